@@ -1,0 +1,205 @@
+/*
+ * webp_amd.h -- C ABI of the MI355X (gfx950) WebP reconstruction backend.
+ *
+ * This is the drop-in boundary for the hot path of fourst4r/webp (pure Haxe).  The reference has
+ * no FFI of its own; the functions below are what a HashLink `.hdll` / hxcpp `@:native` extern
+ * would bind.  Each entry point names the reference code it replaces
+ * (paths relative to the reference's src/webp/).
+ *
+ * Conventions
+ *   - plain `extern "C"`, no exceptions across the boundary; every function returns 0 on success
+ *     and a negative wp_status on failure; wp_last_error() returns the message (the Haxe wrapper
+ *     re-throws it as a String, as the reference does).
+ *   - `*_dev` functions take DEVICE pointers and a hipStream_t (as void*, NULL = default stream);
+ *     they enqueue work and return without synchronising.  The non-`_dev` variants take HOST
+ *     pointers, stage through the library's own buffers and return when the result is in host
+ *     memory; the library never keeps a caller pointer after returning.
+ *   - all batched functions treat their `n` items as independent (a bad descriptor fails the call
+ *     before anything is launched).
+ */
+#ifndef WEBP_AMD_H
+#define WEBP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum wp_status {
+    WP_OK = 0,
+    WP_ERR_INVALID = -1,     /* bad argument / descriptor */
+    WP_ERR_HIP = -2,         /* HIP runtime error (message holds hipGetErrorString) */
+    WP_ERR_FORMAT = -3,      /* malformed stream: the reference's `throw "<String>"` */
+    WP_ERR_EOF = -4,         /* haxe.io.Eof */
+    WP_ERR_NULL = -5,        /* Vp8Decoder.decodeFrame returned null */
+    WP_ERR_NOMEM = -6,
+    WP_ERR_UNSUPPORTED = -7
+} wp_status;
+
+/* ------------------------------------------------------------------------------------------ */
+/* Packed buffer formats (host entropy decode -> device)                                       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* One lossy frame.  Planes are macroblock-padded exactly as Vp8Decoder.ensureImg allocates them
+ * (vp8/Vp8Decoder.hx:186-201): ystride = 16*mbw, uvstride = 8*mbw, 16*mbh / 8*mbh rows. */
+typedef struct wp_vp8_frame {
+    int32_t width, height;      /* FrameHeader.width / height (visible size) */
+    int32_t mbw, mbh;           /* (width+15)>>4, (height+15)>>4 */
+    int32_t filter_type;        /* 0: filterHeader.level == 0, 1: simple, 2: normal (Vp8Decoder.hx:365-371) */
+    int32_t has_alpha;          /* alpha_off is valid */
+    uint32_t mb_base;           /* index of this frame's first record in the MB / filter record arrays */
+    uint32_t reserved;
+    uint64_t coeff_base;        /* index (in 32-byte blocks) of this frame's first coefficient block */
+    uint64_t y_off, u_off, v_off;   /* byte offsets of the frame's planes inside the Y/U/V slabs */
+    uint64_t argb_off;          /* byte offset inside the ARGB slab; tight stride 4*width */
+    uint64_t alpha_off;         /* byte offset inside the alpha slab; tight stride width */
+} wp_vp8_frame;
+
+/* Per-macroblock record, 4 x uint32 (what reconstruct()'s parse half produces, Vp8Decoder.hx:772-808):
+ *   w[0], w[1]  i4 MBs: predY4[j][i] as 4-bit fields, block n = 4*j+i at bits 4*(n&7) of w[n>>3]
+ *               i16 MBs: w[0] bits 0..3 = predY16
+ *   w[2]        bits 0..23  block n has a stored coefficient block (0..15 luma, 16..19 Cb, 20..23 Cr)
+ *               bit 24      a WHT (Y2) block is stored (i16 only)      bit 25  usePredY16
+ *               bits 26..27 predC8
+ *   w[3]        index of the MB's first coefficient block relative to wp_vp8_frame.coeff_base
+ * Coefficient blocks are 16 x int16 in the natural 4x4 order of Vp8Decoder.coeff (dequantised,
+ * sign-truncated to 16 bits, Vp8Decoder.hx:627-631); only blocks with a non-zero value are stored,
+ * in the order WHT, luma 0..15, Cb 0..3, Cr 0..3.  For i16 MBs the luma blocks carry DC = 0; the
+ * device computes the WHT in int32. */
+#define WP_MB_WORDS 4
+#define WP_MB_I16_BIT 25
+#define WP_MB_WHT_BIT 24
+#define WP_MB_C8_SHIFT 26
+
+/* Per-macroblock loop-filter record (Filter.hx:5-10 FilterParam, final state after the whole frame
+ * has been parsed -- SURVEY Q1):  level | ilevel << 8 | hlevel << 16 | inner << 24. */
+
+/* One VP8L transform, in BITSTREAM order (vp8l/Transform.hx:13-19). */
+typedef struct wp_vp8l_transform {
+    int32_t type;               /* 0 Predictor, 1 CrossColor, 2 SubtractGreen, 3 ColorIndexing */
+    int32_t bits;
+    int32_t old_width;
+    int32_t reserved;
+    uint64_t data_off;          /* byte offset of Transform.pix (tile image / expanded palette) in the aux slab */
+    uint64_t data_len;
+} wp_vp8l_transform;
+
+#define WP_VP8L_MAX_TRANSFORMS 4
+typedef struct wp_vp8l_frame {
+    int32_t width, height;      /* final image size (originalW x h, Vp8LDecoder.hx:403-408) */
+    int32_t coded_width;        /* width of the decodePix output (after colour-indexing packing) */
+    int32_t n_transforms;
+    wp_vp8l_transform t[WP_VP8L_MAX_TRANSFORMS];
+    uint64_t pix_off;           /* byte offset of the decodePix output (RGBA, 4*coded_width*height) in the pix slab */
+    uint64_t out_off;           /* byte offset of the result (4*width*height) in the out slab */
+    uint64_t tmp_off;           /* byte offset of a 4*width*height scratch area in the tmp slab */
+} wp_vp8l_frame;
+
+/* One alpha plane (WebPDecoder.hx:357-411). */
+typedef struct wp_alpha_frame {
+    int32_t width, height;      /* alphaStride = width */
+    int32_t filter;             /* 0 none, 1 horizontal, 2 vertical, 3 gradient */
+    int32_t src_is_vp8l_rgba;   /* 1: source is a VP8L RGBA image, take byte 4*i+1 (WebPDecoder.hx:344-349) */
+    uint64_t src_off;           /* byte offset in the source slab */
+    uint64_t dst_off;           /* byte offset in the alpha slab */
+} wp_alpha_frame;
+
+/* ------------------------------------------------------------------------------------------ */
+/* Lifecycle                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+int wp_init(int device);                 /* selects the HIP device for the calling thread; fails if none */
+int wp_shutdown(void);
+int wp_last_error(char* buf, int cap);   /* copies the calling thread's last error message */
+int wp_device_count(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Device-resident batch entry points                                                           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Intra prediction + inverse WHT/DCT for n frames.
+ * Replaces prepareYBR / inverseWHT16 / inverseDCT4* / reconstructMacroblock / copy
+ * (vp8/Vp8Decoder.hx:541-577, 716-770, 810-836, 905-996) and vp8/PredFunc.hx.
+ * frames_host: host copy of the descriptors (used for launch geometry); d_frames: same array on
+ * the device.  d_mb: WP_MB_WORDS uint32 per MB; d_coeff: int16 blocks. Output: unfiltered planes. */
+int wp_vp8_recon_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
+                     const uint32_t* d_mb, const int16_t* d_coeff,
+                     uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, void* stream);
+
+/* In-place loop filter for n frames.  Replaces simpleFilter / normalFilter (vp8/Vp8Decoder.hx:417-486)
+ * and vp8/Filter.hx.  d_filt: one filter record per MB (same indexing as d_mb). */
+int wp_vp8_loopfilter_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
+                          const uint32_t* d_filt, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, void* stream);
+
+/* YUV420 (MB-padded) -> tightly packed A,R,G,B.  Replaces Tools.toArgb (Tools.hx:6-48).
+ * d_alpha may be NULL (all frames opaque); frames with has_alpha == 0 get A = 0xFF. */
+int wp_yuv420_to_argb_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
+                          const uint8_t* d_y, const uint8_t* d_u, const uint8_t* d_v,
+                          const uint8_t* d_alpha, uint8_t* d_argb, void* stream);
+
+/* recon -> loop filter -> convert without leaving the device; the planes keep the filtered YUV
+ * (what ImageData.Yuv420 carries).  Replaces Vp8Decoder.decodeFrame's pixel half + Tools.toArgb. */
+int wp_vp8_decode_to_argb_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
+                              const uint32_t* d_mb, const uint32_t* d_filt, const int16_t* d_coeff,
+                              uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
+                              const uint8_t* d_alpha, uint8_t* d_argb, void* stream);
+
+/* VP8L inverse transform chain + RGBA->ARGB swizzle.  Replaces Transform.hx inversePredictor /
+ * inverseCrossColor / inverseSubtractGreen / inverseColorIndexing, the driver loop
+ * Vp8LDecoder.hx:395-401 and the swizzle WebPDecoder.hx:109-123.
+ * d_pix is consumed (transforms run in place where the reference does). swizzle != 0 applies the
+ * final RGBA->ARGB byte rotation (0 leaves RGBA, which is what readAlpha consumes). */
+int wp_vp8l_inverse_dev(int n, const wp_vp8l_frame* frames_host, const wp_vp8l_frame* d_frames,
+                        uint8_t* d_pix, const uint8_t* d_aux, uint8_t* d_tmp, uint8_t* d_out,
+                        int swizzle, void* stream);
+
+/* Alpha plane: optional green-channel extraction + unfilterAlpha (WebPDecoder.hx:311-411). */
+int wp_alpha_unfilter_dev(int n, const wp_alpha_frame* frames_host, const wp_alpha_frame* d_frames,
+                          const uint8_t* d_src, uint8_t* d_alpha, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Host-pointer entry points (what the Haxe externs call)                                      */
+/* ------------------------------------------------------------------------------------------ */
+/* Same semantics as the _dev variants; all pointers are host memory.  Slab sizes are taken from
+ * the descriptors (max offset + extent). out_y/out_u/out_v receive the filtered planes and may be
+ * NULL when only ARGB is wanted; out_argb may be NULL when only YUV is wanted. */
+int wp_vp8_decode_to_argb(int n, const wp_vp8_frame* frames,
+                          const uint32_t* mb, size_t n_mb, const uint32_t* filt,
+                          const int16_t* coeff, size_t n_coeff_blocks,
+                          uint8_t* out_y, uint8_t* out_u, uint8_t* out_v,
+                          const uint8_t* alpha, uint8_t* out_argb);
+int wp_yuv420_to_argb(int n, const wp_vp8_frame* frames, const uint8_t* y, const uint8_t* u, const uint8_t* v,
+                      const uint8_t* alpha, uint8_t* out_argb);
+int wp_vp8l_inverse(int n, const wp_vp8l_frame* frames, const uint8_t* pix, size_t pix_len,
+                    const uint8_t* aux, size_t aux_len, uint8_t* out, size_t out_len, int swizzle);
+int wp_alpha_unfilter(int n, const wp_alpha_frame* frames, const uint8_t* src, size_t src_len,
+                      uint8_t* alpha, size_t alpha_len);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Host side of the path (C++ mirror of the reference's Haxe host code; the reference toolchain  */
+/* is absent in the build image).  RIFF/VP8/VP8L parsing and entropy decode on the CPU.         */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct wp_parsed wp_parsed;      /* opaque: result of parsing one .webp file */
+
+/* Mirrors WebPDecoder.decode's container walk (WebPDecoder.hx:179-309) and the parse half of
+ * Vp8Decoder / Vp8LDecoder; produces the packed buffers above for every frame in the file. */
+int wp_parse(const uint8_t* data, size_t len, wp_parsed** out);
+void wp_parsed_free(wp_parsed* p);
+/* kind: 0 Yuv420, 1 Argb, 2 Anim (Image.hx:36-46) */
+int wp_parsed_kind(const wp_parsed* p);
+int wp_parsed_width(const wp_parsed* p);
+int wp_parsed_height(const wp_parsed* p);
+int wp_parsed_nframes(const wp_parsed* p);     /* 1 for stills */
+/* per frame i: type 0 lossy / 1 lossless; sizes; pointers into the parsed object's own storage */
+int wp_parsed_frame_info(const wp_parsed* p, int i, int32_t* info /* [16] */);
+const void* wp_parsed_frame_buf(const wp_parsed* p, int i, int which, size_t* len);
+/* VP8L metadata of frame i (and of its VP8L-coded alpha image): sizes and the transform list, 32 ints */
+int wp_parsed_frame_vp8l_meta(const wp_parsed* p, int i, int32_t* meta /* [32] */);
+/* webp.Image.FrameHeader of a lossy frame (Image.hx:10-19), 8 ints */
+int wp_parsed_frame_vp8_header(const wp_parsed* p, int i, int32_t* hdr /* [8] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WEBP_AMD_H */

@@ -1,0 +1,89 @@
+"""ctypes binding of libwebp_amd.so (the C ABI in include/webp_amd.h).  There is no CPU fallback:
+if the library is missing, or no HIP device is present when a compute entry point is called,
+the call fails loudly."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libwebp_amd.so")
+
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+class Vp8Frame(ctypes.Structure):          # wp_vp8_frame
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("mbw", ctypes.c_int32), ("mbh", ctypes.c_int32),
+                ("filter_type", ctypes.c_int32), ("has_alpha", ctypes.c_int32), ("mb_base", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32), ("coeff_base", ctypes.c_uint64), ("y_off", ctypes.c_uint64),
+                ("u_off", ctypes.c_uint64), ("v_off", ctypes.c_uint64), ("argb_off", ctypes.c_uint64),
+                ("alpha_off", ctypes.c_uint64)]
+
+
+class Vp8lTransform(ctypes.Structure):     # wp_vp8l_transform
+    _fields_ = [("type", ctypes.c_int32), ("bits", ctypes.c_int32), ("old_width", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("data_off", ctypes.c_uint64), ("data_len", ctypes.c_uint64)]
+
+
+class Vp8lFrame(ctypes.Structure):         # wp_vp8l_frame
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("coded_width", ctypes.c_int32),
+                ("n_transforms", ctypes.c_int32), ("t", Vp8lTransform * 4), ("pix_off", ctypes.c_uint64),
+                ("out_off", ctypes.c_uint64), ("tmp_off", ctypes.c_uint64)]
+
+
+class AlphaFrame(ctypes.Structure):        # wp_alpha_frame
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("filter", ctypes.c_int32),
+                ("src_is_vp8l_rgba", ctypes.c_int32), ("src_off", ctypes.c_uint64), ("dst_off", ctypes.c_uint64)]
+
+
+class WebPError(Exception):
+    """Raised with the message the reference would `throw` (plus the native status code)."""
+    def __init__(self, code, msg):
+        super().__init__("%s (status %d)" % (msg, code))
+        self.code = code
+        self.msg = msg
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError("libwebp_amd.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C webp_amd/csrc`. There is no CPU fallback." % SO_PATH)
+    L = ctypes.CDLL(SO_PATH)
+    vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    L.wp_init.argtypes = [i32]
+    L.wp_last_error.argtypes = [ctypes.c_char_p, i32]
+    L.wp_vp8_recon_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.wp_vp8_loopfilter_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
+    L.wp_yuv420_to_argb_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.wp_vp8_decode_to_argb_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.wp_vp8l_inverse_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.wp_alpha_unfilter_dev.argtypes = [i32, vp, vp, vp, vp, vp]
+    L.wp_vp8_decode_to_argb.argtypes = [i32, vp, vp, sz, vp, vp, sz, vp, vp, vp, vp, vp]
+    L.wp_yuv420_to_argb.argtypes = [i32, vp, vp, vp, vp, vp, vp]
+    L.wp_vp8l_inverse.argtypes = [i32, vp, vp, sz, vp, sz, vp, sz, i32]
+    L.wp_alpha_unfilter.argtypes = [i32, vp, vp, sz, vp, sz]
+    L.wp_parse.argtypes = [vp, sz, ctypes.POINTER(vp)]
+    L.wp_parsed_free.argtypes = [vp]
+    L.wp_parsed_free.restype = None
+    for f in ("wp_parsed_kind", "wp_parsed_width", "wp_parsed_height", "wp_parsed_nframes"):
+        getattr(L, f).argtypes = [vp]
+    L.wp_parsed_frame_info.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_int32)]
+    L.wp_parsed_frame_buf.argtypes = [vp, i32, i32, ctypes.POINTER(sz)]
+    L.wp_parsed_frame_buf.restype = vp
+    _lib = L
+    return L
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    lib().wp_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc != 0:
+        raise WebPError(rc, last_error())

@@ -1,0 +1,415 @@
+// C ABI of the library (include/webp_amd.h): argument checking, launch geometry, host staging and the
+// batch assembler that turns parsed files into the packed slabs the kernels consume.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "host/host.h"
+
+// kernel launchers (kernels/*.hip)
+extern "C" {
+int wpk_launch_vp8_recon(int n, int grid, const wp_vp8_frame* d_frames, const void* d_mb, const int16_t* d_coeff,
+                         uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, hipStream_t stream);
+int wpk_launch_vp8_filter(int n, int grid, const wp_vp8_frame* d_frames, const uint32_t* d_filt,
+                          uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, hipStream_t stream);
+int wpk_launch_yuv420_to_argb(int n, int grid_x, const wp_vp8_frame* d_frames, const uint8_t* d_y, const uint8_t* d_u,
+                              const uint8_t* d_v, const uint8_t* d_alpha, uint8_t* d_argb, hipStream_t stream);
+int wpk_launch_vp8l(int n, const wp_vp8l_frame* frames_host, const wp_vp8l_frame* d_frames, uint8_t* d_pix, const uint8_t* d_aux,
+                    uint8_t* d_tmp, uint8_t* d_out, int swizzle, hipStream_t stream);
+int wpk_launch_alpha(int n, const wp_alpha_frame* frames_host, const wp_alpha_frame* d_frames, const uint8_t* d_src, uint8_t* d_alpha,
+                     hipStream_t stream);
+}
+
+namespace {
+
+thread_local std::string g_error;
+int g_wavefront_grid = 0;      // workgroups for the wavefront-scheduled kernels (set by wp_init)
+int g_cus = 0;
+
+int fail(int code, const std::string& msg) { g_error = msg; return code; }
+int hip_fail(hipError_t e, const char* what) { return fail(WP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hip_fail(e_, #expr); } while (0)
+
+int ensure_init() {
+    if (g_cus > 0) return WP_OK;
+    return wp_init(-1);
+}
+
+int check_vp8_frames(int n, const wp_vp8_frame* f) {
+    if (n < 0 || (n > 0 && !f)) return fail(WP_ERR_INVALID, "bad frame array");
+    for (int i = 0; i < n; ++i) {
+        const wp_vp8_frame& a = f[i];
+        if (a.mbw <= 0 || a.mbh <= 0 || a.mbw > 1024 || a.mbh > 1024 || a.width <= 0 || a.height <= 0 ||
+            a.width > 16 * a.mbw || a.height > 16 * a.mbh || a.filter_type < 0 || a.filter_type > 2)
+            return fail(WP_ERR_INVALID, "bad wp_vp8_frame at index " + std::to_string(i));
+        if ((a.y_off & 15) || (a.u_off & 7) || (a.v_off & 7) || (a.argb_off & 3))
+            return fail(WP_ERR_INVALID, "misaligned plane offset in wp_vp8_frame " + std::to_string(i));
+    }
+    return WP_OK;
+}
+
+}  // namespace
+
+namespace wp { void set_error(const std::string& msg) { g_error = msg; } }
+
+extern "C" {
+
+int wp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int wp_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(WP_ERR_HIP, "no HIP device available (the HIP path has no CPU fallback)");
+    if (device >= 0) {
+        if (device >= n) return fail(WP_ERR_INVALID, "device index out of range");
+        HIP_TRY(hipSetDevice(device));
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    g_cus = prop.multiProcessorCount;
+    g_wavefront_grid = g_cus * 2;      // 2 workgroups of 8 wavefronts per CU (LDS and VGPR budget allow it)
+    return WP_OK;
+}
+
+int wp_shutdown(void) { return WP_OK; }
+
+int wp_last_error(char* buf, int cap) {
+    if (!buf || cap <= 0) return int(g_error.size());
+    std::snprintf(buf, size_t(cap), "%s", g_error.c_str());
+    return int(g_error.size());
+}
+
+int wp_vp8_recon_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint32_t* d_mb, const int16_t* d_coeff,
+                     uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, void* stream) {
+    int rc = ensure_init(); if (rc) return rc;
+    rc = check_vp8_frames(n, fh); if (rc) return rc;
+    if (n == 0) return WP_OK;
+    if (!fd || !d_mb || !d_y || !d_u || !d_v) return fail(WP_ERR_INVALID, "null device pointer");
+    const int grid = std::min(n, g_wavefront_grid);
+    const int e = wpk_launch_vp8_recon(n, grid, fd, d_mb, d_coeff, d_y, d_u, d_v, hipStream_t(stream));
+    if (e) return hip_fail(hipError_t(e), "vp8_recon launch");
+    return WP_OK;
+}
+
+int wp_vp8_loopfilter_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint32_t* d_filt,
+                          uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, void* stream) {
+    int rc = ensure_init(); if (rc) return rc;
+    rc = check_vp8_frames(n, fh); if (rc) return rc;
+    if (n == 0) return WP_OK;
+    if (!fd || !d_filt || !d_y || !d_u || !d_v) return fail(WP_ERR_INVALID, "null device pointer");
+    bool any = false;
+    for (int i = 0; i < n; ++i) any = any || fh[i].filter_type != 0;
+    if (!any) return WP_OK;
+    const int grid = std::min(n, g_wavefront_grid);
+    const int e = wpk_launch_vp8_filter(n, grid, fd, d_filt, d_y, d_u, d_v, hipStream_t(stream));
+    if (e) return hip_fail(hipError_t(e), "vp8_filter launch");
+    return WP_OK;
+}
+
+int wp_yuv420_to_argb_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint8_t* d_y, const uint8_t* d_u,
+                          const uint8_t* d_v, const uint8_t* d_alpha, uint8_t* d_argb, void* stream) {
+    int rc = ensure_init(); if (rc) return rc;
+    rc = check_vp8_frames(n, fh); if (rc) return rc;
+    if (n == 0) return WP_OK;
+    if (!fd || !d_y || !d_u || !d_v || !d_argb) return fail(WP_ERR_INVALID, "null device pointer");
+    long long max_quads = 1;
+    for (int i = 0; i < n; ++i) {
+        if (fh[i].has_alpha && !d_alpha) return fail(WP_ERR_INVALID, "frame has alpha but no alpha slab was given");
+        max_quads = std::max(max_quads, (long long)((fh[i].width + 3) / 4) * fh[i].height);
+    }
+    // the y dimension of the grid is the frame index (<= 65535 per launch)
+    for (int first = 0; first < n; first += 65535) {
+        const int cnt = std::min(65535, n - first);
+        long long gx = (max_quads + 255) / 256;
+        const long long cap = std::max(1LL, (long long)g_cus * 32 / std::max(1, std::min(cnt, g_cus * 32)));
+        gx = std::min(gx, std::max(cap, 1LL) * 4);
+        const int e = wpk_launch_yuv420_to_argb(cnt, int(gx), fd + first, d_y, d_u, d_v, d_alpha, d_argb, hipStream_t(stream));
+        if (e) return hip_fail(hipError_t(e), "yuv420_to_argb launch");
+    }
+    return WP_OK;
+}
+
+int wp_vp8_decode_to_argb_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint32_t* d_mb, const uint32_t* d_filt,
+                              const int16_t* d_coeff, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, const uint8_t* d_alpha,
+                              uint8_t* d_argb, void* stream) {
+    int rc = wp_vp8_recon_dev(n, fh, fd, d_mb, d_coeff, d_y, d_u, d_v, stream);
+    if (rc) return rc;
+    rc = wp_vp8_loopfilter_dev(n, fh, fd, d_filt, d_y, d_u, d_v, stream);
+    if (rc) return rc;
+    if (d_argb) rc = wp_yuv420_to_argb_dev(n, fh, fd, d_y, d_u, d_v, d_alpha, d_argb, stream);
+    return rc;
+}
+
+int wp_vp8l_inverse_dev(int n, const wp_vp8l_frame* fh, const wp_vp8l_frame* fd, uint8_t* d_pix, const uint8_t* d_aux,
+                        uint8_t* d_tmp, uint8_t* d_out, int swizzle, void* stream) {
+    int rc = ensure_init(); if (rc) return rc;
+    if (n < 0 || (n > 0 && (!fh || !fd || !d_pix || !d_out))) return fail(WP_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i) {
+        const wp_vp8l_frame& a = fh[i];
+        if (a.width <= 0 || a.height <= 0 || a.coded_width <= 0 || a.n_transforms < 0 || a.n_transforms > WP_VP8L_MAX_TRANSFORMS ||
+            (a.pix_off & 15) || (a.out_off & 15) || (a.tmp_off & 15))
+            return fail(WP_ERR_INVALID, "bad wp_vp8l_frame at index " + std::to_string(i));
+        for (int k = 0; k < a.n_transforms; ++k)
+            if (a.t[k].type < 0 || a.t[k].type > 3 || a.t[k].bits < 0 || a.t[k].bits > 9 || (a.t[k].data_off & 3))
+                return fail(WP_ERR_INVALID, "bad transform in wp_vp8l_frame " + std::to_string(i));
+    }
+    if (n == 0) return WP_OK;
+    const int e = wpk_launch_vp8l(n, fh, fd, d_pix, d_aux, d_tmp, d_out, swizzle, hipStream_t(stream));
+    if (e) return hip_fail(hipError_t(e), "vp8l launch");
+    return WP_OK;
+}
+
+int wp_alpha_unfilter_dev(int n, const wp_alpha_frame* fh, const wp_alpha_frame* fd, const uint8_t* d_src, uint8_t* d_alpha, void* stream) {
+    int rc = ensure_init(); if (rc) return rc;
+    if (n < 0 || (n > 0 && (!fh || !fd || !d_src || !d_alpha))) return fail(WP_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i)
+        if (fh[i].width <= 0 || fh[i].height <= 0 || fh[i].filter < 0 || fh[i].filter > 3)
+            return fail(WP_ERR_INVALID, "bad wp_alpha_frame at index " + std::to_string(i));
+    if (n == 0) return WP_OK;
+    const int e = wpk_launch_alpha(n, fh, fd, d_src, d_alpha, hipStream_t(stream));
+    if (e) return hip_fail(hipError_t(e), "alpha launch");
+    return WP_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Host-pointer variants and the batch assembler
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        n = bytes;
+        if (bytes == 0) bytes = 16;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc"); }
+        return WP_OK;
+    }
+    int upload(const void* src, size_t bytes) {
+        int rc = alloc(bytes); if (rc) return rc;
+        if (bytes) HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        return WP_OK;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Vp8Extents { size_t y = 0, u = 0, v = 0, argb = 0, alpha = 0; };
+Vp8Extents vp8_extents(int n, const wp_vp8_frame* f) {
+    Vp8Extents e;
+    for (int i = 0; i < n; ++i) {
+        const size_t ysz = size_t(256) * f[i].mbw * f[i].mbh, csz = size_t(64) * f[i].mbw * f[i].mbh;
+        e.y = std::max(e.y, size_t(f[i].y_off) + ysz);
+        e.u = std::max(e.u, size_t(f[i].u_off) + csz);
+        e.v = std::max(e.v, size_t(f[i].v_off) + csz);
+        e.argb = std::max(e.argb, size_t(f[i].argb_off) + size_t(4) * f[i].width * f[i].height);
+        if (f[i].has_alpha) e.alpha = std::max(e.alpha, size_t(f[i].alpha_off) + size_t(f[i].width) * f[i].height);
+    }
+    return e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wp_vp8_decode_to_argb(int n, const wp_vp8_frame* frames, const uint32_t* mb, size_t n_mb, const uint32_t* filt,
+                          const int16_t* coeff, size_t n_coeff_blocks, uint8_t* out_y, uint8_t* out_u, uint8_t* out_v,
+                          const uint8_t* alpha, uint8_t* out_argb) {
+    int rc = ensure_init(); if (rc) return rc;
+    rc = check_vp8_frames(n, frames); if (rc) return rc;
+    if (n == 0) return WP_OK;
+    if (!mb || !filt) return fail(WP_ERR_INVALID, "null record array");
+    for (int i = 0; i < n; ++i) {
+        if (size_t(frames[i].mb_base) + size_t(frames[i].mbw) * frames[i].mbh > n_mb) return fail(WP_ERR_INVALID, "mb_base out of range");
+        if (frames[i].coeff_base > n_coeff_blocks) return fail(WP_ERR_INVALID, "coeff_base out of range");
+    }
+    const Vp8Extents ex = vp8_extents(n, frames);
+    DevBuf dfr, dmb, dfl, dco, dy, du, dv, da, dargb;
+    if ((rc = dfr.upload(frames, sizeof(wp_vp8_frame) * size_t(n)))) return rc;
+    if ((rc = dmb.upload(mb, n_mb * 16))) return rc;
+    if ((rc = dfl.upload(filt, n_mb * 4))) return rc;
+    if ((rc = dco.upload(coeff, n_coeff_blocks * 32))) return rc;
+    if ((rc = dy.alloc(ex.y)) || (rc = du.alloc(ex.u)) || (rc = dv.alloc(ex.v))) return rc;
+    if (ex.alpha) { if (!alpha) return fail(WP_ERR_INVALID, "alpha slab missing"); if ((rc = da.upload(alpha, ex.alpha))) return rc; }
+    if (out_argb && (rc = dargb.alloc(ex.argb))) return rc;
+    rc = wp_vp8_decode_to_argb_dev(n, frames, dfr.as<wp_vp8_frame>(), dmb.as<uint32_t>(), dfl.as<uint32_t>(), dco.as<int16_t>(),
+                                   dy.as<uint8_t>(), du.as<uint8_t>(), dv.as<uint8_t>(), ex.alpha ? da.as<uint8_t>() : nullptr,
+                                   out_argb ? dargb.as<uint8_t>() : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (out_y) HIP_TRY(hipMemcpy(out_y, dy.p, ex.y, hipMemcpyDeviceToHost));
+    if (out_u) HIP_TRY(hipMemcpy(out_u, du.p, ex.u, hipMemcpyDeviceToHost));
+    if (out_v) HIP_TRY(hipMemcpy(out_v, dv.p, ex.v, hipMemcpyDeviceToHost));
+    if (out_argb) HIP_TRY(hipMemcpy(out_argb, dargb.p, ex.argb, hipMemcpyDeviceToHost));
+    return WP_OK;
+}
+
+int wp_yuv420_to_argb(int n, const wp_vp8_frame* frames, const uint8_t* y, const uint8_t* u, const uint8_t* v,
+                      const uint8_t* alpha, uint8_t* out_argb) {
+    int rc = ensure_init(); if (rc) return rc;
+    rc = check_vp8_frames(n, frames); if (rc) return rc;
+    if (n == 0) return WP_OK;
+    if (!y || !u || !v || !out_argb) return fail(WP_ERR_INVALID, "null pointer");
+    const Vp8Extents ex = vp8_extents(n, frames);
+    DevBuf dfr, dy, du, dv, da, dargb;
+    if ((rc = dfr.upload(frames, sizeof(wp_vp8_frame) * size_t(n)))) return rc;
+    if ((rc = dy.upload(y, ex.y)) || (rc = du.upload(u, ex.u)) || (rc = dv.upload(v, ex.v))) return rc;
+    if (ex.alpha) { if (!alpha) return fail(WP_ERR_INVALID, "alpha slab missing"); if ((rc = da.upload(alpha, ex.alpha))) return rc; }
+    if ((rc = dargb.alloc(ex.argb))) return rc;
+    rc = wp_yuv420_to_argb_dev(n, frames, dfr.as<wp_vp8_frame>(), dy.as<uint8_t>(), du.as<uint8_t>(), dv.as<uint8_t>(),
+                               ex.alpha ? da.as<uint8_t>() : nullptr, dargb.as<uint8_t>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_argb, dargb.p, ex.argb, hipMemcpyDeviceToHost));
+    return WP_OK;
+}
+
+int wp_vp8l_inverse(int n, const wp_vp8l_frame* frames, const uint8_t* pix, size_t pix_len, const uint8_t* aux, size_t aux_len,
+                    uint8_t* out, size_t out_len, int swizzle) {
+    int rc = ensure_init(); if (rc) return rc;
+    if (n < 0 || (n > 0 && (!frames || !pix || !out))) return fail(WP_ERR_INVALID, "bad argument");
+    if (n == 0) return WP_OK;
+    size_t tmp_len = 0;
+    for (int i = 0; i < n; ++i) {
+        const wp_vp8l_frame& a = frames[i];
+        if (a.width <= 0 || a.height <= 0 || a.coded_width <= 0) return fail(WP_ERR_INVALID, "bad wp_vp8l_frame");
+        if (size_t(a.pix_off) + size_t(4) * a.coded_width * a.height > pix_len) return fail(WP_ERR_INVALID, "pix slab too small");
+        if (size_t(a.out_off) + size_t(4) * a.width * a.height > out_len) return fail(WP_ERR_INVALID, "out slab too small");
+        for (int k = 0; k < a.n_transforms && k < WP_VP8L_MAX_TRANSFORMS; ++k)
+            if (size_t(a.t[k].data_off) + size_t(a.t[k].data_len) > aux_len) return fail(WP_ERR_INVALID, "aux slab too small");
+        tmp_len = std::max(tmp_len, size_t(a.tmp_off) + size_t(4) * a.width * a.height);
+    }
+    DevBuf dfr, dpix, daux, dtmp, dout;
+    if ((rc = dfr.upload(frames, sizeof(wp_vp8l_frame) * size_t(n)))) return rc;
+    if ((rc = dpix.upload(pix, pix_len)) || (rc = daux.upload(aux, aux_len))) return rc;
+    if ((rc = dtmp.alloc(tmp_len)) || (rc = dout.alloc(out_len))) return rc;
+    rc = wp_vp8l_inverse_dev(n, frames, dfr.as<wp_vp8l_frame>(), dpix.as<uint8_t>(), daux.as<uint8_t>(), dtmp.as<uint8_t>(),
+                             dout.as<uint8_t>(), swizzle, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, out_len, hipMemcpyDeviceToHost));
+    return WP_OK;
+}
+
+int wp_alpha_unfilter(int n, const wp_alpha_frame* frames, const uint8_t* src, size_t src_len, uint8_t* alpha, size_t alpha_len) {
+    int rc = ensure_init(); if (rc) return rc;
+    if (n < 0 || (n > 0 && (!frames || !src || !alpha))) return fail(WP_ERR_INVALID, "bad argument");
+    if (n == 0) return WP_OK;
+    for (int i = 0; i < n; ++i) {
+        const wp_alpha_frame& a = frames[i];
+        if (a.width <= 0 || a.height <= 0) return fail(WP_ERR_INVALID, "bad wp_alpha_frame");
+        const size_t px = size_t(a.width) * a.height;
+        if (size_t(a.src_off) + px * (a.src_is_vp8l_rgba ? 4 : 1) > src_len) return fail(WP_ERR_INVALID, "source slab too small");
+        if (size_t(a.dst_off) + px > alpha_len) return fail(WP_ERR_INVALID, "alpha slab too small");
+    }
+    DevBuf dfr, dsrc, dal;
+    if ((rc = dfr.upload(frames, sizeof(wp_alpha_frame) * size_t(n)))) return rc;
+    if ((rc = dsrc.upload(src, src_len)) || (rc = dal.alloc(alpha_len))) return rc;
+    rc = wp_alpha_unfilter_dev(n, frames, dfr.as<wp_alpha_frame>(), dsrc.as<uint8_t>(), dal.as<uint8_t>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(alpha, dal.p, alpha_len, hipMemcpyDeviceToHost));
+    return WP_OK;
+}
+
+// ---- host parse objects ----
+int wp_parse(const uint8_t* data, size_t len, wp_parsed** out) {
+    if (!out) return fail(WP_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (!data && len) return fail(WP_ERR_INVALID, "null data");
+    wp_parsed* p = new (std::nothrow) wp_parsed();
+    if (!p) return fail(WP_ERR_NOMEM, "out of memory");
+    std::string err;
+    int rc;
+    try {
+        rc = wp::parse_webp(data, len, *p, err);
+    } catch (const std::bad_alloc&) {
+        rc = WP_ERR_NOMEM; err = "out of memory";
+    }
+    if (rc) { delete p; return fail(rc, err); }
+    *out = p;
+    return WP_OK;
+}
+void wp_parsed_free(wp_parsed* p) { delete p; }
+int wp_parsed_kind(const wp_parsed* p) { return p ? p->kind : -1; }
+int wp_parsed_width(const wp_parsed* p) { return p ? p->width : 0; }
+int wp_parsed_height(const wp_parsed* p) { return p ? p->height : 0; }
+int wp_parsed_nframes(const wp_parsed* p) { return p ? int(p->frames.size()) : 0; }
+
+// info: [0] type, [1] width, [2] height, [3] mbw, [4] mbh, [5] filter_type, [6] has_alpha, [7] x, [8] y, [9] duration,
+//       [10] blend, [11] dispose, [12] n_transforms, [13] coded_width, [14] alpha filter, [15] alpha is vp8l-coded
+int wp_parsed_frame_info(const wp_parsed* p, int i, int32_t* info) {
+    if (!p || i < 0 || size_t(i) >= p->frames.size() || !info) return fail(WP_ERR_INVALID, "bad frame index");
+    const wp::ParsedFrame& f = p->frames[size_t(i)];
+    info[0] = f.type; info[1] = f.width; info[2] = f.height;
+    info[3] = f.vp8.mbw; info[4] = f.vp8.mbh; info[5] = f.vp8.filter_type; info[6] = f.alpha.present ? 1 : 0;
+    info[7] = f.x; info[8] = f.y; info[9] = f.duration; info[10] = f.blend; info[11] = f.dispose;
+    info[12] = int(f.vp8l.transforms.size()); info[13] = f.vp8l.coded_width; info[14] = f.alpha.filter; info[15] = f.alpha.vp8l ? 1 : 0;
+    return WP_OK;
+}
+
+// which: 0 MB records, 1 filter records, 2 coefficient blocks, 3 VP8L pix, 4 raw alpha bytes, 5 alpha VP8L pix,
+//        10+k: data of VP8L transform k, 20+k: data of the alpha image's transform k
+const void* wp_parsed_frame_buf(const wp_parsed* p, int i, int which, size_t* len) {
+    if (len) *len = 0;
+    if (!p || i < 0 || size_t(i) >= p->frames.size()) return nullptr;
+    const wp::ParsedFrame& f = p->frames[size_t(i)];
+    auto ret = [&](const void* ptr, size_t n) { if (len) *len = n; return ptr; };
+    switch (which) {
+    case 0: return ret(f.vp8.mb.data(), f.vp8.mb.size() * 4);
+    case 1: return ret(f.vp8.filt.data(), f.vp8.filt.size() * 4);
+    case 2: return ret(f.vp8.coeff.data(), f.vp8.coeff.size() * 2);
+    case 3: return ret(f.vp8l.pix.data(), f.vp8l.pix.size());
+    case 4: return ret(f.alpha.raw.data(), f.alpha.raw.size());
+    case 5: return ret(f.alpha.coded.pix.data(), f.alpha.coded.pix.size());
+    default:
+        if (which >= 10 && which < 14 && size_t(which - 10) < f.vp8l.transforms.size())
+            return ret(f.vp8l.transforms[size_t(which - 10)].pix.data(), f.vp8l.transforms[size_t(which - 10)].pix.size());
+        if (which >= 20 && which < 24 && size_t(which - 20) < f.alpha.coded.transforms.size())
+            return ret(f.alpha.coded.transforms[size_t(which - 20)].pix.data(), f.alpha.coded.transforms[size_t(which - 20)].pix.size());
+        return nullptr;
+    }
+}
+
+// meta: [0] vp8l width, [1] height, [2] n_transforms, [4+3k..6+3k] (type, bits, old_width) of transform k;
+//       [16..18] and [20+3k..22+3k]: the same for the VP8L-coded alpha image of the frame
+int wp_parsed_frame_vp8l_meta(const wp_parsed* p, int i, int32_t* meta) {
+    if (!p || i < 0 || size_t(i) >= p->frames.size() || !meta) return fail(WP_ERR_INVALID, "bad frame index");
+    const wp::ParsedFrame& f = p->frames[size_t(i)];
+    std::memset(meta, 0, 32 * sizeof(int32_t));
+    const wp::Vp8lPacked* src[2] = {&f.vp8l, &f.alpha.coded};
+    for (int s = 0; s < 2; ++s) {
+        int32_t* m = meta + 16 * s;
+        m[0] = src[s]->width; m[1] = src[s]->height; m[2] = int32_t(src[s]->transforms.size());
+        for (size_t k = 0; k < src[s]->transforms.size() && k < 4; ++k) {
+            m[4 + 3 * k] = src[s]->transforms[k].type; m[5 + 3 * k] = src[s]->transforms[k].bits; m[6 + 3 * k] = src[s]->transforms[k].old_width;
+        }
+    }
+    if (!f.alpha.vp8l) { meta[16] = f.alpha.width; meta[17] = f.alpha.height; }
+    return WP_OK;
+}
+
+// hdr: FrameHeader of a lossy frame (Image.hx:10-19): keyFrame, versionNumber, showFrame, firstPartitionLen, width, height, xScale, yScale
+int wp_parsed_frame_vp8_header(const wp_parsed* p, int i, int32_t* hdr) {
+    if (!p || i < 0 || size_t(i) >= p->frames.size() || !hdr) return fail(WP_ERR_INVALID, "bad frame index");
+    const wp::Vp8Packed& v = p->frames[size_t(i)].vp8;
+    hdr[0] = v.keyFrame; hdr[1] = v.versionNumber; hdr[2] = v.showFrame; hdr[3] = v.firstPartitionLen;
+    hdr[4] = v.width; hdr[5] = v.height; hdr[6] = v.xScale; hdr[7] = v.yScale;
+    return WP_OK;
+}
+
+}  // extern "C"

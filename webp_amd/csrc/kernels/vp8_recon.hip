@@ -1,0 +1,447 @@
+// VP8 intra prediction + inverse WHT/DCT for a batch of frames (gfx950).
+//
+// Replaces prepareYBR / inverseWHT16 / inverseDCT4* / reconstructMacroblock / copy of the reference
+// (vp8/Vp8Decoder.hx:541-577, 716-770, 810-836, 905-996) and vp8/PredFunc.hx.
+//
+// Schedule: macroblock (x, y) needs (x-1,y), (x,y-1), (x-1,y-1) and (x+1,y-1), so it becomes ready
+// at anti-diagonal step s = x + 2y.  One wavefront owns a band of 4 macroblock rows: lane group
+// g = lane>>4 works on row 4*band+g at column s-2g, so the four groups run the 2:1 skew in
+// lockstep and need no synchronisation among themselves.  Inside a group, lane l owns 4x4 luma
+// block l (and lanes 0-3 / 8-11 a chroma block).  Neighbour pixels live in a per-group LDS tile
+// with the same geometry as the reference's `ybr` workspace (Reconstruct.hx:3-12), which keeps the
+// border rules (0x7f / 0x81 fills, top-right replication, the rows-4/8/12 top-right copy) literal.
+// Bands of one frame are pipelined across the wavefronts of a workgroup: the band below waits on
+// an LDS progress word and reads the bottom row of the band above from the output planes
+// (workgroup-scope release/acquire, same CU).
+#include "wp_device.h"
+
+namespace wpk {
+
+struct ReconTile {              // bytes; row pitch 32 so that 4-pixel groups are dword aligned
+    uint8_t y[17][32];          // row 0: [3] corner, [4..19] top, [20..23] top-right; rows 1..16: [3] left, [4..19] pixels
+    uint8_t c[9][32];           // Cb at cols 3 | 4..11, Cr at cols 19 | 20..27; row 0 is the top border
+};
+struct ReconWaveLds {
+    ReconTile tile[kBandRows];
+    uint32_t ring[kBandRows][4][8];   // ring[g][col & 3]: bottom row of the MB above group g: Y (4 dwords), U (2), V (2)
+};
+
+__device__ __forceinline__ uint32_t& tile32(uint8_t* row, int col) { return *reinterpret_cast<uint32_t*>(row + col); }
+
+__device__ __forceinline__ int avg3(int a, int b, int c) { return (a + 2 * b + c + 2) >> 2; }
+__device__ __forceinline__ int avg2(int a, int b) { return (a + b + 1) >> 1; }
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) { return uint32_t(a) | uint32_t(b) << 8 | uint32_t(c) << 16 | uint32_t(d) << 24; }
+__device__ __forceinline__ int byteof(uint32_t v, int i) { return int((v >> (8 * i)) & 0xff); }
+
+// Wrapping 32-bit multiply, arithmetic >> 16 (Vp8Decoder.hx:913-914).
+__device__ __forceinline__ int mul16(int a, int c) { return int(uint32_t(a) * uint32_t(c)) >> 16; }
+
+typedef short short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t as_u32(short2_t v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ short2_t as_s2(uint32_t v) { return __builtin_bit_cast(short2_t, v); }
+
+// Residual of one 4x4 block: inverseDCT4 without the "+ prediction, clip8" tail
+// (Vp8Decoder.hx:905-935).  Row j comes back as two packed int16 pairs:
+// even[j] = (r[j][0], r[j][2]), odd[j] = (r[j][1], r[j][3]), each clamped to [-255, 255]
+// (clip8(pred + r) cannot tell larger magnitudes apart, pred being in 0..255).
+__device__ __forceinline__ void idct_residual(const int (&c)[16], uint32_t (&even)[4], uint32_t (&odd)[4]) {
+    const int c1 = 85627, c2 = 35468;
+    int m[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int a = c[i] + c[8 + i];
+        const int b = c[i] - c[8 + i];
+        const int cc = mul16(c[4 + i], c2) - mul16(c[12 + i], c1);
+        const int d = mul16(c[4 + i], c1) + mul16(c[12 + i], c2);
+        m[i][0] = a + d; m[i][1] = b + cc; m[i][2] = b - cc; m[i][3] = a - d;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int dc = m[0][j] + 4;
+        const int a = dc + m[2][j];
+        const int b = dc - m[2][j];
+        const int cc = mul16(m[1][j], c2) - mul16(m[3][j], c1);
+        const int d = mul16(m[1][j], c1) + mul16(m[3][j], c2);
+        const int r0 = clampi((a + d) >> 3, -255, 255), r1 = clampi((b + cc) >> 3, -255, 255);
+        const int r2 = clampi((b - cc) >> 3, -255, 255), r3 = clampi((a - d) >> 3, -255, 255);
+        even[j] = (uint32_t(r0) & 0xffff) | (uint32_t(r2) << 16);
+        odd[j] = (uint32_t(r1) & 0xffff) | (uint32_t(r3) << 16);
+    }
+}
+
+// clip8(pred + residual) for one row of four pixels (Vp8Decoder.hx:930-933, 991-996).
+__device__ __forceinline__ uint32_t add_clip_row(uint32_t pred, uint32_t even, uint32_t odd) {
+    const short2_t zero = {0, 0}, top = {255, 255};
+    short2_t lo = as_s2(pred & 0x00ff00ffu) + as_s2(even);
+    short2_t hi = as_s2((pred >> 8) & 0x00ff00ffu) + as_s2(odd);
+    lo = __builtin_elementwise_min(__builtin_elementwise_max(lo, zero), top);
+    hi = __builtin_elementwise_min(__builtin_elementwise_max(hi, zero), top);
+    return as_u32(lo) | (as_u32(hi) << 8);
+}
+
+// Loads a stored coefficient block (16 x int16, natural order) into ints.
+__device__ __forceinline__ void load_block(const int16_t* p, int (&c)[16]) {
+    const uint4 a = reinterpret_cast<const uint4*>(p)[0];
+    const uint4 b = reinterpret_cast<const uint4*>(p)[1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { c[2 * i] = int(int16_t(w[i] & 0xffff)); c[2 * i + 1] = int(w[i]) >> 16; }
+}
+
+// inverseWHT16 (Vp8Decoder.hx:960-989): returns the DC that lands in luma block n = 4*i + k,
+// computed in int32 without truncation.
+__device__ __forceinline__ int wht_dc(const int (&c)[16], int n) {
+    const int i = n >> 2, k = n & 3;
+    int mm[4];      // m[4*i + j], j = 0..3
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int a0 = c[j] + c[12 + j], a1 = c[4 + j] + c[8 + j], a2 = c[4 + j] - c[8 + j], a3 = c[j] - c[12 + j];
+        mm[j] = i == 0 ? a0 + a1 : i == 1 ? a3 + a2 : i == 2 ? a0 - a1 : a3 - a2;
+    }
+    const int dc = mm[0] + 3;
+    const int a0 = dc + mm[3], a1 = mm[1] + mm[2], a2 = mm[1] - mm[2], a3 = dc - mm[3];
+    const int v = k == 0 ? a0 + a1 : k == 1 ? a3 + a2 : k == 2 ? a0 - a1 : a3 - a2;
+    return v >> 3;
+}
+
+// The ten 4x4 luma predictors (PredFunc.hx:118-418).  top8 = the 8 pixels above (4 above the
+// block + 4 above-right), left4 = the 4 pixels to the left (byte r = row r), corner = above-left.
+__device__ __forceinline__ void pred4x4(int mode, uint32_t top_lo, uint32_t top_hi, uint32_t left4, int corner, uint32_t (&row)[4]) {
+    const int T0 = byteof(top_lo, 0), T1 = byteof(top_lo, 1), T2 = byteof(top_lo, 2), T3 = byteof(top_lo, 3);
+    const int T4 = byteof(top_hi, 0), T5 = byteof(top_hi, 1), T6 = byteof(top_hi, 2), T7 = byteof(top_hi, 3);
+    const int L0 = byteof(left4, 0), L1 = byteof(left4, 1), L2 = byteof(left4, 2), L3 = byteof(left4, 3);
+    const int C = corner;
+    switch (mode) {
+    case 0: {   // DC
+        const int v = (T0 + T1 + T2 + T3 + L0 + L1 + L2 + L3 + 4) >> 3;
+        row[0] = row[1] = row[2] = row[3] = uint32_t(v) * 0x01010101u;
+        break; }
+    case 1: {   // TM
+        const int L[4] = {L0, L1, L2, L3};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d = L[r] - C;
+            row[r] = pack4(clampi(d + T0, 0, 255), clampi(d + T1, 0, 255), clampi(d + T2, 0, 255), clampi(d + T3, 0, 255));
+        }
+        break; }
+    case 2: {   // VE (smoothed)
+        const uint32_t v = pack4(avg3(C, T0, T1), avg3(T0, T1, T2), avg3(T1, T2, T3), avg3(T2, T3, T4));
+        row[0] = row[1] = row[2] = row[3] = v;
+        break; }
+    case 3: {   // HE (smoothed)
+        row[0] = uint32_t(avg3(C, L0, L1)) * 0x01010101u;
+        row[1] = uint32_t(avg3(L0, L1, L2)) * 0x01010101u;
+        row[2] = uint32_t(avg3(L1, L2, L3)) * 0x01010101u;
+        row[3] = uint32_t(avg3(L2, L3, L3)) * 0x01010101u;
+        break; }
+    case 4: {   // RD
+        const int srq = avg3(L3, L2, L1), rqp = avg3(L2, L1, L0), qpa = avg3(L1, L0, C), pab = avg3(L0, C, T0);
+        const int abc = avg3(C, T0, T1), bcd = avg3(T0, T1, T2), cde = avg3(T1, T2, T3);
+        row[0] = pack4(pab, abc, bcd, cde);
+        row[1] = pack4(qpa, pab, abc, bcd);
+        row[2] = pack4(rqp, qpa, pab, abc);
+        row[3] = pack4(srq, rqp, qpa, pab);
+        break; }
+    case 5: {   // VR
+        const int ab = avg2(C, T0), bc = avg2(T0, T1), cd = avg2(T1, T2), de = avg2(T2, T3);
+        const int rqp = avg3(L2, L1, L0), qpa = avg3(L1, L0, C), pab = avg3(L0, C, T0);
+        const int abc = avg3(C, T0, T1), bcd = avg3(T0, T1, T2), cde = avg3(T1, T2, T3);
+        row[0] = pack4(ab, bc, cd, de);
+        row[1] = pack4(pab, abc, bcd, cde);
+        row[2] = pack4(qpa, ab, bc, cd);
+        row[3] = pack4(rqp, pab, abc, bcd);
+        break; }
+    case 6: {   // LD
+        const int abc = avg3(T0, T1, T2), bcd = avg3(T1, T2, T3), cde = avg3(T2, T3, T4), def = avg3(T3, T4, T5);
+        const int efg = avg3(T4, T5, T6), fgh = avg3(T5, T6, T7), ghh = avg3(T6, T7, T7);
+        row[0] = pack4(abc, bcd, cde, def);
+        row[1] = pack4(bcd, cde, def, efg);
+        row[2] = pack4(cde, def, efg, fgh);
+        row[3] = pack4(def, efg, fgh, ghh);
+        break; }
+    case 7: {   // VL
+        const int ab = avg2(T0, T1), bc = avg2(T1, T2), cd = avg2(T2, T3), de = avg2(T3, T4);
+        const int abc = avg3(T0, T1, T2), bcd = avg3(T1, T2, T3), cde = avg3(T2, T3, T4), def = avg3(T3, T4, T5);
+        const int efg = avg3(T4, T5, T6), fgh = avg3(T5, T6, T7);
+        row[0] = pack4(ab, bc, cd, de);
+        row[1] = pack4(abc, bcd, cde, def);
+        row[2] = pack4(bc, cd, de, efg);
+        row[3] = pack4(bcd, cde, def, fgh);
+        break; }
+    case 8: {   // HD
+        const int sr = avg2(L3, L2), rq = avg2(L2, L1), qp = avg2(L1, L0), pa = avg2(L0, C);
+        const int srq = avg3(L3, L2, L1), rqp = avg3(L2, L1, L0), qpa = avg3(L1, L0, C), pab = avg3(L0, C, T0);
+        const int abc = avg3(C, T0, T1), bcd = avg3(T0, T1, T2);
+        row[0] = pack4(pa, pab, abc, bcd);
+        row[1] = pack4(qp, qpa, pa, pab);
+        row[2] = pack4(rq, rqp, qp, qpa);
+        row[3] = pack4(sr, srq, rq, rqp);
+        break; }
+    default: {  // 9: HU
+        const int pq = avg2(L0, L1), qr = avg2(L1, L2), rs = avg2(L2, L3);
+        const int pqr = avg3(L0, L1, L2), qrs = avg3(L1, L2, L3), rss = avg3(L2, L3, L3), sss = L3;
+        row[0] = pack4(pq, pqr, qr, qrs);
+        row[1] = pack4(qr, qrs, rs, rss);
+        row[2] = pack4(rs, rss, sss, sss);
+        row[3] = pack4(sss, sss, sss, sss);
+        break; }
+    }
+}
+
+// 8x8 / 16x16 predictors restricted to one 4x4 sub-block (PredFunc.hx:420-572).  `mode` has
+// already been through checkTopLeftPred (PredFunc.hx:57-68); dcval is the block-wide DC value.
+__device__ __forceinline__ void pred_large(int mode, uint32_t top4, uint32_t left4, int corner, int dcval, uint32_t (&row)[4]) {
+    if (mode == 1) {            // TM
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d = byteof(left4, r) - corner;
+            row[r] = pack4(clampi(d + byteof(top4, 0), 0, 255), clampi(d + byteof(top4, 1), 0, 255),
+                           clampi(d + byteof(top4, 2), 0, 255), clampi(d + byteof(top4, 3), 0, 255));
+        }
+    } else if (mode == 2) {     // VE
+        row[0] = row[1] = row[2] = row[3] = top4;
+    } else if (mode == 3) {     // HE
+#pragma unroll
+        for (int r = 0; r < 4; ++r) row[r] = uint32_t(byteof(left4, r)) * 0x01010101u;
+    } else {                    // DC and its top/left variants
+        row[0] = row[1] = row[2] = row[3] = uint32_t(dcval) * 0x01010101u;
+    }
+}
+
+// Sum over the 16 lanes of a group (row of 16 lanes in DPP terms).
+__device__ __forceinline__ int group_sum16(int v) {
+    v += __shfl_xor(v, 1, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 8, 16);
+    return v;
+}
+
+__global__ __launch_bounds__(kWavesPerWG * kWave)
+void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, const uint4* __restrict__ mb,
+                      const int16_t* __restrict__ coeff, uint8_t* Yp, uint8_t* Up, uint8_t* Vp) {
+    __shared__ ReconWaveLds lds_all[kWavesPerWG];
+    __shared__ uint32_t progress[kWavesPerWG];
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4;            // macroblock row within the band
+    const int l = lane & 15;            // 4x4 luma block owned by this lane
+    const int bj = l >> 2, bi = l & 3;
+    ReconWaveLds& lds = lds_all[wave];
+    ReconTile& T = lds.tile[g];
+
+    if (threadIdx.x < kWavesPerWG) progress[threadIdx.x] = 0;
+    __syncthreads();
+
+    uint32_t seq = 1;                   // running band number of this workgroup (identical in all its waves)
+    for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const wp_vp8_frame fr = frames[f];
+        const int mbw = fr.mbw, mbh = fr.mbh;
+        const int ystride = 16 * mbw, cstride = 8 * mbw;
+        uint8_t* const Y = Yp + fr.y_off;
+        uint8_t* const U = Up + fr.u_off;
+        uint8_t* const V = Vp + fr.v_off;
+        const int n_bands = (mbh + kBandRows - 1) / kBandRows;
+
+        for (int band = 0; band < n_bands; ++band) {
+            const uint32_t q = seq + uint32_t(band);
+            if (int(q % kWavesPerWG) != wave) continue;
+            const int y = band * kBandRows + g;
+            const bool row_ok = y < mbh;
+            const bool has_above = band > 0;
+            const bool has_below = band + 1 < n_bands;
+            const int prev_wave = (wave + kWavesPerWG - 1) % kWavesPerWG;
+            const int rows_here = min(kBandRows, mbh - band * kBandRows);
+            const int n_steps = mbw + 2 * (rows_here - 1);
+
+            for (int s = 0; s < n_steps; ++s) {
+                const int x = s - 2 * g;
+                const bool act = row_ok && x >= 0 && x < mbw;
+
+                // ---- top context of group 0 comes from the band above, through the output planes ----
+                if (has_above && s < mbw) {
+                    wait_progress(&progress[prev_wave], ((q - 1) << kSeqShift) | uint32_t(min(s + 2, mbw)));
+                    if (g == 0 && l < 8) {
+                        const uint8_t* src0 = l < 4 ? Y + size_t(16 * y - 1) * ystride + 4 * l
+                                            : l < 6 ? U + size_t(8 * y - 1) * cstride + 4 * (l - 4)
+                                                    : V + size_t(8 * y - 1) * cstride + 4 * (l - 6);
+                        const int colbytes = l < 4 ? 16 : 8;
+                        if (s == 0) lds.ring[0][0][l] = *reinterpret_cast<const uint32_t*>(src0);
+                        if (s + 1 < mbw) lds.ring[0][(s + 1) & 3][l] = *reinterpret_cast<const uint32_t*>(src0 + size_t(s + 1) * colbytes);
+                    }
+                }
+
+                // ---- macroblock record and residuals (independent of the neighbours) ----
+                uint4 rec = make_uint4(0, 0, 0, 0);
+                if (act) rec = mb[size_t(fr.mb_base) + size_t(y) * mbw + x];
+                const uint32_t w2 = rec.z;
+                const bool i16 = (w2 >> WP_MB_I16_BIT) & 1;
+                const int has_wht = (w2 >> WP_MB_WHT_BIT) & 1;
+                const int16_t* cbase = coeff + (size_t(fr.coeff_base) + rec.w) * 16;
+
+                uint32_t ev[4] = {0, 0, 0, 0}, od[4] = {0, 0, 0, 0};          // luma residual of block l
+                {
+                    int c[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) c[k] = 0;
+                    const bool present = act && ((w2 >> l) & 1);
+                    if (present) load_block(cbase + size_t(has_wht + __popc(w2 & ((1u << l) - 1u))) * 16, c);
+                    int dc16 = 0;
+                    if (act && i16 && has_wht) {
+                        int wc[16];
+                        load_block(cbase, wc);
+                        dc16 = wht_dc(wc, l);
+                        c[0] = dc16;
+                    }
+                    if (present || dc16 != 0) idct_residual(c, ev, od);
+                }
+                const bool chroma_lane = (l & 4) == 0;                         // lanes 0-3: Cb blocks, 8-11: Cr blocks
+                const int cn = 16 + (l & 3) + ((l & 8) ? 4 : 0);
+                uint32_t cev[4] = {0, 0, 0, 0}, cod[4] = {0, 0, 0, 0};
+                if (act && chroma_lane && ((w2 >> cn) & 1)) {
+                    int c[16];
+                    load_block(cbase + size_t(has_wht + __popc(w2 & ((1u << cn) - 1u))) * 16, c);
+                    idct_residual(c, cev, cod);
+                }
+
+                uint32_t px[4] = {0, 0, 0, 0}, cpx[4] = {0, 0, 0, 0};
+                if (act) {
+                    // ---- prepareYBR (Vp8Decoder.hx:541-577): left column, then top row ----
+                    {
+                        const uint8_t fillL = 0x81;
+                        T.y[l][3] = x == 0 ? fillL : T.y[l][19];
+                        if (l == 0) T.y[16][3] = x == 0 ? fillL : T.y[16][19];
+                        if (l < 9) {
+                            T.c[l][3] = x == 0 ? fillL : T.c[l][11];
+                            T.c[l][19] = x == 0 ? fillL : T.c[l][27];
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (y == 0) {
+                        if (l < 5) tile32(T.y[0], 4 + 4 * l) = 0x7f7f7f7fu;
+                        if (l == 5) { T.y[0][3] = 0x7f; T.c[0][3] = 0x7f; T.c[0][19] = 0x7f; }
+                        if (l == 6 || l == 7) tile32(T.c[0], 4 + 4 * (l - 6)) = 0x7f7f7f7fu;
+                        if (l == 8 || l == 9) tile32(T.c[0], 20 + 4 * (l - 8)) = 0x7f7f7f7fu;
+                    } else {
+                        const uint32_t* slot = lds.ring[g][x & 3];
+                        if (l < 4) tile32(T.y[0], 4 + 4 * l) = slot[l];
+                        if (l == 4) tile32(T.y[0], 20) = x == mbw - 1 ? (slot[3] >> 24) * 0x01010101u : lds.ring[g][(x + 1) & 3][0];
+                        if (l == 6 || l == 7) tile32(T.c[0], 4 + 4 * (l - 6)) = slot[4 + (l - 6)];
+                        if (l == 8 || l == 9) tile32(T.c[0], 20 + 4 * (l - 8)) = slot[6 + (l - 8)];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (l >= 1 && l <= 3) tile32(T.y[4 * l], 20) = tile32(T.y[0], 20);   // rows 4/8/12 keep the MB's top-right (:572-576)
+                    __builtin_amdgcn_wave_barrier();
+
+                    // ---- luma ----
+                    if (i16) {
+                        int mode = int(rec.x & 15);
+                        // checkTopLeftPred (PredFunc.hx:57-68): 10 = DCTop (mby==0), 11 = DCLeft (mbx==0), 12 = DCTopLeft
+                        const int tsum = group_sum16(int(T.y[0][4 + l]));
+                        const int lsum = group_sum16(int(T.y[1 + l][3]));
+                        int dcv = (tsum + lsum + 16) >> 5;
+                        if (mode == 0) {
+                            if (x == 0) dcv = y == 0 ? 0x80 : (tsum + 8) >> 4;     // "DCLeft" sums the top row
+                            else if (y == 0) dcv = (lsum + 8) >> 4;                // "DCTop" sums the left column
+                        }
+                        const uint32_t top4 = tile32(T.y[0], 4 + 4 * bi);
+                        const uint32_t left4 = pack4(T.y[4 * bj + 1][3], T.y[4 * bj + 2][3], T.y[4 * bj + 3][3], T.y[4 * bj + 4][3]);
+                        uint32_t pr[4];
+                        pred_large(mode, top4, left4, int(T.y[0][3]), dcv, pr);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            px[r] = add_clip_row(pr[r], ev[r], od[r]);
+                            tile32(T.y[4 * bj + 1 + r], 4 + 4 * bi) = px[r];
+                        }
+                    }
+                }
+                // i4: blocks in raster order predict from already reconstructed neighbours; block (bj,bi)
+                // is ready at mini-step bi + 2*bj (it needs (bj,bi-1), (bj-1,bi) and (bj-1,bi+1)).
+                if (__builtin_amdgcn_ballot_w64(act && !i16) != 0) {
+                    const int my_t = bi + 2 * bj;
+                    const int mode4 = int(((l < 8 ? rec.x : rec.y) >> (4 * (l & 7))) & 15);
+                    for (int t = 0; t < 10; ++t) {
+                        if (act && !i16 && t == my_t) {
+                            uint8_t* above = T.y[4 * bj];
+                            const uint32_t top_lo = tile32(above, 4 + 4 * bi);
+                            const uint32_t top_hi = tile32(above, 8 + 4 * bi);
+                            const int corner = above[3 + 4 * bi];
+                            const uint32_t left4 = pack4(T.y[4 * bj + 1][3 + 4 * bi], T.y[4 * bj + 2][3 + 4 * bi],
+                                                         T.y[4 * bj + 3][3 + 4 * bi], T.y[4 * bj + 4][3 + 4 * bi]);
+                            uint32_t pr[4];
+                            pred4x4(mode4, top_lo, top_hi, left4, corner, pr);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                px[r] = add_clip_row(pr[r], ev[r], od[r]);
+                                tile32(T.y[4 * bj + 1 + r], 4 + 4 * bi) = px[r];
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                if (act) {
+                    // ---- chroma: one 8x8 predictor per plane, four 4x4 residual blocks each ----
+                    const int c8 = int((w2 >> WP_MB_C8_SHIFT) & 3);
+                    const int plane = l >> 3;                 // lanes 0..7 sum Cb borders, 8..15 Cr borders
+                    const int cb = plane ? 20 : 4;
+                    int tsum = int(T.c[0][cb + (l & 7)]), lsum = int(T.c[1 + (l & 7)][cb - 1]);
+                    tsum += __shfl_xor(tsum, 1, 16); lsum += __shfl_xor(lsum, 1, 16);
+                    tsum += __shfl_xor(tsum, 2, 16); lsum += __shfl_xor(lsum, 2, 16);
+                    tsum += __shfl_xor(tsum, 4, 16); lsum += __shfl_xor(lsum, 4, 16);
+                    int dcv = (tsum + lsum + 8) >> 4;
+                    if (c8 == 0) {
+                        if (x == 0) dcv = y == 0 ? 0x80 : (tsum + 4) >> 3;
+                        else if (y == 0) dcv = (lsum + 4) >> 3;
+                    }
+                    if (chroma_lane) {
+                        const int cj = (l >> 1) & 1, ci = l & 1;
+                        const uint32_t top4 = tile32(T.c[0], cb + 4 * ci);
+                        const uint32_t left4 = pack4(T.c[4 * cj + 1][cb - 1], T.c[4 * cj + 2][cb - 1], T.c[4 * cj + 3][cb - 1], T.c[4 * cj + 4][cb - 1]);
+                        uint32_t pr[4];
+                        pred_large(c8, top4, left4, int(T.c[0][cb - 1]), dcv, pr);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            cpx[r] = add_clip_row(pr[r], cev[r], cod[r]);
+                            tile32(T.c[4 * cj + 1 + r], cb + 4 * ci) = cpx[r];
+                        }
+                    }
+
+                    // ---- write back (Vp8Decoder.hx:812-821) ----
+                    uint8_t* yd = Y + size_t(16 * y + 4 * bj) * ystride + 16 * x + 4 * bi;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) *reinterpret_cast<uint32_t*>(yd + size_t(r) * ystride) = px[r];
+                    if (chroma_lane) {
+                        const int cj = (l >> 1) & 1, ci = l & 1;
+                        uint8_t* cd = (plane ? V : U) + size_t(8 * y + 4 * cj) * cstride + 8 * x + 4 * ci;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) *reinterpret_cast<uint32_t*>(cd + size_t(r) * cstride) = cpx[r];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---- hand the bottom row to the group below (same wavefront, two steps later) ----
+                if (act && g + 1 < kBandRows && l < 8) {
+                    const uint32_t v = l < 4 ? tile32(T.y[16], 4 + 4 * l)
+                                     : l < 6 ? tile32(T.c[8], 4 + 4 * (l - 4))
+                                             : tile32(T.c[8], 20 + 4 * (l - 6));
+                    lds.ring[g + 1][x & 3][l] = v;
+                }
+                // ---- tell the band below how far this band's last row has got ----
+                if (has_below) {
+                    const int done = s - 2 * (kBandRows - 1) + 1;
+                    if (done >= 1) publish_progress(&progress[wave], (q << kSeqShift) | uint32_t(done));
+                }
+            }
+        }
+        seq += uint32_t(n_bands);
+    }
+}
+
+}  // namespace wpk
+
+extern "C" int wpk_launch_vp8_recon(int n, int grid, const wp_vp8_frame* d_frames, const void* d_mb, const int16_t* d_coeff,
+                                    uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, hipStream_t stream) {
+    hipLaunchKernelGGL(wpk::vp8_recon_kernel, dim3(grid), dim3(wpk::kWavesPerWG * wpk::kWave), 0, stream,
+                       n, d_frames, reinterpret_cast<const uint4*>(d_mb), d_coeff, d_y, d_u, d_v);
+    return int(hipGetLastError());
+}

@@ -1,0 +1,423 @@
+"""Host-side mirror of the reference's public surface, above the C ABI.
+
+Reference (Haxe)                          here
+  webp.WebPDecoder.decode(Input):Image     WebPDecoder.decode(bytes) -> Image          (WebPDecoder.hx:179-244)
+  webp.Tools.toArgb(Image):Image           Tools.toArgb(Image) -> Image                (Tools.hx:6-48)
+  webp.Image / FrameHeader / ImageData     Image / FrameHeader / Yuv420 | Argb | Anim  (Image.hx:5-46)
+
+The reference's toolchain (Haxe) is absent from the build image, so this mirror is written in Python
+(batch assembly, API objects) over the library's own C++ host code (container walk + entropy decode,
+webp_amd/csrc/host/).  All pixel work happens in the HIP kernels; nothing here computes pixels.
+Errors surface as WebPError carrying the String the reference would throw.
+"""
+import ctypes
+from dataclasses import dataclass, field
+from typing import List, Optional, Union
+
+import numpy as np
+
+from . import _lib
+from ._lib import Vp8Frame, Vp8lFrame, AlphaFrame, check, lib
+
+
+# ---------------------------------------------------------------- Image.hx mirror
+@dataclass
+class FrameHeader:
+    keyFrame: bool = True
+    versionNumber: int = 0
+    showFrame: bool = True
+    firstPartitionLen: int = 0
+    width: int = 0
+    height: int = 0
+    xScale: int = 0
+    yScale: int = 0
+
+
+@dataclass
+class AnimFrameHeader:
+    x: int = 0
+    y: int = 0
+    width: int = 0
+    height: int = 0
+    duration: int = 0
+    blend: bool = False
+    dispose: bool = False
+
+
+@dataclass
+class Yuv420:
+    y: np.ndarray
+    ystride: int
+    u: np.ndarray
+    v: np.ndarray
+    uvstride: int
+    a: Optional[np.ndarray] = None
+
+
+@dataclass
+class Argb:
+    pix: np.ndarray
+    stride: int
+
+
+@dataclass
+class AnimImage:
+    header: AnimFrameHeader
+    data: Union[Yuv420, Argb]
+
+
+@dataclass
+class Anim:
+    frames: List[AnimImage] = field(default_factory=list)
+
+
+ImageData = Union[Yuv420, Argb, Anim]
+
+
+@dataclass
+class Image:
+    header: FrameHeader
+    data: ImageData
+
+
+# ---------------------------------------------------------------- parsed files (host entropy decode results)
+def _align(v, a):
+    return (v + a - 1) // a * a
+
+
+class ParsedFrame:
+    """One frame of a parsed file: numpy views of the packed buffers owned by the native object."""
+
+    def __init__(self, owner, index):
+        L = lib()
+        info = (ctypes.c_int32 * 16)()
+        check(L.wp_parsed_frame_info(owner._h, index, info))
+        (self.type, self.width, self.height, self.mbw, self.mbh, self.filter_type, self.has_alpha, self.x, self.y,
+         self.duration, self.blend, self.dispose, self.n_transforms, self.coded_width, self.alpha_filter,
+         self.alpha_is_vp8l) = [int(v) for v in info]
+        self._owner = owner
+        self._index = index
+
+    def buf(self, which, dtype=np.uint8):
+        n = ctypes.c_size_t()
+        p = lib().wp_parsed_frame_buf(self._owner._h, self._index, which, ctypes.byref(n))
+        if not p or n.value == 0:
+            return np.zeros(0, dtype=dtype)
+        raw = (ctypes.c_uint8 * n.value).from_address(p)
+        return np.frombuffer(raw, dtype=dtype)       # view; the ParsedFile keeps the memory alive
+
+
+class ParsedFile:
+    def __init__(self, data: bytes):
+        L = lib()
+        h = ctypes.c_void_p()
+        check(L.wp_parse(data, len(data), ctypes.byref(h)))
+        self._h = h
+        self.kind = L.wp_parsed_kind(h)          # 0 Yuv420, 1 Argb, 2 Anim
+        self.width = L.wp_parsed_width(h)
+        self.height = L.wp_parsed_height(h)
+        self.frames = [ParsedFrame(self, i) for i in range(L.wp_parsed_nframes(h))]
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().wp_parsed_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def parse(data: bytes) -> ParsedFile:
+    """Container walk + entropy decode on the CPU (mirrors the parse half of WebPDecoder.decode)."""
+    return ParsedFile(data)
+
+
+# ---------------------------------------------------------------- batch assembly
+class LossyBatch:
+    """Packed slabs for a list of lossy frames (the buffers wp_vp8_decode_to_argb[_dev] consumes)."""
+
+    def __init__(self, frames: List[ParsedFrame], with_alpha: Optional[List[bool]] = None):
+        n = len(frames)
+        self.n = n
+        self.desc = (Vp8Frame * max(n, 1))()
+        mbs, filts, coeffs = [], [], []
+        mb_base = coeff_base = 0
+        y_off = u_off = v_off = argb_off = alpha_off = 0
+        for i, f in enumerate(frames):
+            d = self.desc[i]
+            d.width, d.height, d.mbw, d.mbh = f.width, f.height, f.mbw, f.mbh
+            d.filter_type = f.filter_type
+            d.has_alpha = 1 if (with_alpha[i] if with_alpha is not None else False) else 0
+            d.mb_base, d.coeff_base = mb_base, coeff_base
+            d.y_off, d.u_off, d.v_off, d.argb_off, d.alpha_off = y_off, u_off, v_off, argb_off, alpha_off
+            mb = f.buf(0, np.uint32)
+            co = f.buf(2, np.int16)
+            mbs.append(mb)
+            filts.append(f.buf(1, np.uint32))
+            coeffs.append(co)
+            nmb = f.mbw * f.mbh
+            assert mb.size == 4 * nmb
+            mb_base += nmb
+            coeff_base += co.size // 16
+            y_off += _align(256 * nmb, 256)
+            u_off += _align(64 * nmb, 256)
+            v_off += _align(64 * nmb, 256)
+            argb_off += _align(4 * f.width * f.height, 256)
+            if d.has_alpha:
+                alpha_off += _align(f.width * f.height, 256)
+        self.mb = np.concatenate(mbs) if mbs else np.zeros(0, np.uint32)
+        self.filt = np.concatenate(filts) if filts else np.zeros(0, np.uint32)
+        self.coeff = np.concatenate(coeffs) if coeffs else np.zeros(0, np.int16)
+        if self.coeff.size == 0:
+            self.coeff = np.zeros(16, np.int16)
+        self.n_mb = mb_base
+        self.n_coeff_blocks = self.coeff.size // 16
+        self.y_bytes, self.u_bytes, self.v_bytes = y_off, u_off, v_off
+        self.argb_bytes, self.alpha_bytes = argb_off, alpha_off
+
+    def input_bytes(self):
+        """Bytes the device reads per pass: descriptors + records + coefficients."""
+        return ctypes.sizeof(Vp8Frame) * self.n + self.mb.nbytes + self.filt.nbytes + self.n_coeff_blocks * 32
+
+
+_TRANSFORM_BUF0 = 10
+
+
+class LosslessBatch:
+    """Packed slabs for a list of VP8L images (wp_vp8l_inverse[_dev]).  `which_pix`/`which_t0` select the
+    frame's own image (3 / 10) or its VP8L-coded alpha image (5 / 20)."""
+
+    def __init__(self, frames: List[ParsedFrame], alpha_image=False):
+        n = len(frames)
+        self.n = n
+        self.desc = (Vp8lFrame * max(n, 1))()
+        which_pix, which_t0 = (5, 20) if alpha_image else (3, _TRANSFORM_BUF0)
+        pix, aux = [], []
+        pix_off = aux_off = out_off = 0
+        L = lib()
+        for i, f in enumerate(frames):
+            d = self.desc[i]
+            p = f.buf(which_pix)
+            if alpha_image:
+                width, height = f.alpha_width, f.alpha_height
+            else:
+                width, height = f.vp8l_width, f.vp8l_height
+            d.width, d.height = width, height
+            d.pix_off, d.out_off, d.tmp_off = pix_off, out_off, out_off
+            tinfo = f.alpha_transforms if alpha_image else f.transforms
+            d.n_transforms = len(tinfo)
+            coded_width = width
+            for k, (ttype, bits, old_width) in enumerate(tinfo):
+                t = d.t[k]
+                t.type, t.bits, t.old_width = ttype, bits, old_width
+                data = f.buf(which_t0 + k)
+                t.data_off, t.data_len = aux_off, data.size
+                aux.append(data)
+                pad = _align(data.size, 16) - data.size
+                if pad:
+                    aux.append(np.zeros(pad, np.uint8))
+                aux_off += data.size + pad
+                if ttype == 3:
+                    coded_width = (old_width + (1 << bits) - 1) >> bits
+            d.coded_width = p.size // (4 * height) if height else 0
+            assert d.coded_width == coded_width, (d.coded_width, coded_width)
+            pix.append(p)
+            pad = _align(p.size, 256) - p.size
+            if pad:
+                pix.append(np.zeros(pad, np.uint8))
+            pix_off += p.size + pad
+            out_off += _align(4 * width * height, 256)
+        self.pix = np.concatenate(pix) if pix else np.zeros(16, np.uint8)
+        self.aux = np.concatenate(aux) if aux else np.zeros(16, np.uint8)
+        if self.aux.size == 0:
+            self.aux = np.zeros(16, np.uint8)
+        self.out_bytes = max(out_off, 16)
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def _frame_transforms(f: ParsedFrame):
+    """Reads the transform list of a frame from the native object (type, bits, old_width)."""
+    return f.transforms
+
+
+# transform metadata is fetched lazily through a tiny extra query encoded in wp_parsed_frame_buf lens;
+# the native side exposes it via wp_parsed_frame_info2 (see capi.cpp).
+def _load_vp8l_meta(f: ParsedFrame):
+    L = lib()
+    meta = (ctypes.c_int32 * 32)()
+    check(L.wp_parsed_frame_vp8l_meta(f._owner._h, f._index, meta))
+    f.vp8l_width, f.vp8l_height, nt = int(meta[0]), int(meta[1]), int(meta[2])
+    f.transforms = [(int(meta[4 + 3 * k]), int(meta[5 + 3 * k]), int(meta[6 + 3 * k])) for k in range(nt)]
+    f.alpha_width, f.alpha_height, nat = int(meta[16]), int(meta[17]), int(meta[18])
+    f.alpha_transforms = [(int(meta[20 + 3 * k]), int(meta[21 + 3 * k]), int(meta[22 + 3 * k])) for k in range(nat)]
+
+
+def decode_batch(files: List[ParsedFile]):
+    """Decodes every frame of every parsed file on the current HIP device.  Returns one Image per file,
+    with Yuv420 planes (lossy) / Argb pixels (lossless) exactly as WebPDecoder.decode would hold them."""
+    L = lib()
+    L.wp_parsed_frame_vp8l_meta.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]
+    flat = [(fi, k, fr) for fi, pf in enumerate(files) for k, fr in enumerate(pf.frames)]
+    for _, _, fr in flat:
+        _load_vp8l_meta(fr)
+    results = {}
+
+    # 1. alpha planes of lossy frames (WebPDecoder.readAlpha + unfilterAlpha)
+    alpha_frames = [t for t in flat if t[2].type == 0 and t[2].has_alpha]
+    alpha_planes = {}
+    if alpha_frames:
+        coded = [t for t in alpha_frames if t[2].alpha_is_vp8l]
+        rgba = None
+        lb = None
+        if coded:
+            lb = LosslessBatch([t[2] for t in coded], alpha_image=True)
+            rgba = np.empty(lb.out_bytes, np.uint8)
+            check(L.wp_vp8l_inverse(lb.n, lb.desc, _np_ptr(lb.pix), lb.pix.size, _np_ptr(lb.aux), lb.aux.size,
+                                    _np_ptr(rgba), rgba.size, 0))
+        desc = (AlphaFrame * len(alpha_frames))()
+        srcs, src_off, dst_off, ci = [], 0, 0, 0
+        for i, (_, _, fr) in enumerate(alpha_frames):
+            d = desc[i]
+            d.width, d.height, d.filter = fr.alpha_width, fr.alpha_height, fr.alpha_filter
+            d.dst_off = dst_off
+            if fr.alpha_is_vp8l:
+                o = int(lb.desc[ci].out_off)
+                ci += 1
+                s = rgba[o:o + 4 * d.width * d.height]
+                d.src_is_vp8l_rgba = 1
+            else:
+                s = fr.buf(4)
+                d.src_is_vp8l_rgba = 0
+            d.src_off = src_off
+            srcs.append(s)
+            pad = _align(s.size, 16) - s.size
+            if pad:
+                srcs.append(np.zeros(pad, np.uint8))
+            src_off += s.size + pad
+            dst_off += _align(d.width * d.height, 16)
+        src = np.concatenate(srcs)
+        out = np.empty(max(dst_off, 16), np.uint8)
+        check(L.wp_alpha_unfilter(len(alpha_frames), desc, _np_ptr(src), src.size, _np_ptr(out), out.size))
+        for i, t in enumerate(alpha_frames):
+            o = int(desc[i].dst_off)
+            alpha_planes[(t[0], t[1])] = out[o:o + desc[i].width * desc[i].height].copy()
+
+    # 2. lossy frames: recon + loop filter (Vp8Decoder.decodeFrame's pixel half)
+    lossy = [t for t in flat if t[2].type == 0]
+    if lossy:
+        b = LossyBatch([t[2] for t in lossy])
+        y = np.empty(max(b.y_bytes, 16), np.uint8)
+        u = np.empty(max(b.u_bytes, 16), np.uint8)
+        v = np.empty(max(b.v_bytes, 16), np.uint8)
+        check(L.wp_vp8_decode_to_argb(b.n, b.desc, _np_ptr(b.mb), b.n_mb, _np_ptr(b.filt), _np_ptr(b.coeff), b.n_coeff_blocks,
+                                      _np_ptr(y), _np_ptr(u), _np_ptr(v), None, None))
+        for i, (fi, k, fr) in enumerate(lossy):
+            d = b.desc[i]
+            nmb = fr.mbw * fr.mbh
+            results[(fi, k)] = Yuv420(y[d.y_off:d.y_off + 256 * nmb].copy(), 16 * fr.mbw,
+                                      u[d.u_off:d.u_off + 64 * nmb].copy(), v[d.v_off:d.v_off + 64 * nmb].copy(), 8 * fr.mbw,
+                                      alpha_planes.get((fi, k)))
+
+    # 3. lossless frames: inverse transforms + swizzle (Vp8LDecoder.decode tail + readVp8l)
+    lossless = [t for t in flat if t[2].type == 1]
+    if lossless:
+        lb = LosslessBatch([t[2] for t in lossless])
+        out = np.empty(lb.out_bytes, np.uint8)
+        check(L.wp_vp8l_inverse(lb.n, lb.desc, _np_ptr(lb.pix), lb.pix.size, _np_ptr(lb.aux), lb.aux.size,
+                                _np_ptr(out), out.size, 1))
+        for i, (fi, k, fr) in enumerate(lossless):
+            d = lb.desc[i]
+            results[(fi, k)] = Argb(out[d.out_off:d.out_off + 4 * d.width * d.height].copy(), 4 * d.width)
+
+    images = []
+    for fi, pf in enumerate(files):
+        if pf.kind == 2:
+            frames = [AnimImage(AnimFrameHeader(fr.x, fr.y, fr.width, fr.height, fr.duration, bool(fr.blend), bool(fr.dispose)),
+                                results[(fi, k)]) for k, fr in enumerate(pf.frames)]
+            images.append(Image(FrameHeader(width=pf.width, height=pf.height), Anim(frames)))
+        else:
+            images.append(Image(FrameHeader(width=pf.width, height=pf.height), results[(fi, 0)]))
+    return images
+
+
+class WebPDecoder:
+    @staticmethod
+    def decode(data: bytes) -> Image:
+        """WebPDecoder.decode (WebPDecoder.hx:179-244): host parse, then GPU reconstruction."""
+        return decode_batch([parse(data)])[0]
+
+
+def _yuv_to_argb(items):
+    """items: list of (Yuv420, width, height) -> list of tightly packed ARGB arrays (one GPU call)."""
+    L = lib()
+    n = len(items)
+    desc = (Vp8Frame * n)()
+    ys, us, vs, als = [], [], [], []
+    y_off = u_off = v_off = argb_off = alpha_off = 0
+    any_alpha = False
+    for i, (d, w, h) in enumerate(items):
+        mbw, mbh = d.ystride // 16, d.y.size // (d.ystride * 16)
+        if d.ystride != 16 * mbw or d.uvstride != 8 * mbw:
+            raise _lib.WebPError(-1, "Yuv420 planes must be macroblock padded (ystride = 16*mbw)")
+        f = desc[i]
+        f.width, f.height, f.mbw, f.mbh = w, h, mbw, mbh
+        f.y_off, f.u_off, f.v_off, f.argb_off, f.alpha_off = y_off, u_off, v_off, argb_off, alpha_off
+        f.has_alpha = 1 if d.a is not None else 0
+        for lst, arr, al in ((ys, d.y, 256), (us, d.u, 256), (vs, d.v, 256)):
+            lst.append(arr)
+            pad = _align(arr.size, al) - arr.size
+            if pad:
+                lst.append(np.zeros(pad, np.uint8))
+        y_off += _align(d.y.size, 256)
+        u_off += _align(d.u.size, 256)
+        v_off += _align(d.v.size, 256)
+        argb_off += _align(4 * w * h, 256)
+        if d.a is not None:
+            if d.a.size < w * h:
+                raise _lib.WebPError(-1, "alpha plane smaller than width*height")
+            any_alpha = True
+            a = d.a[:w * h]
+            als.append(a)
+            pad = _align(a.size, 256) - a.size
+            if pad:
+                als.append(np.zeros(pad, np.uint8))
+            alpha_off += _align(a.size, 256)
+    y, u, v = np.concatenate(ys), np.concatenate(us), np.concatenate(vs)
+    al = np.concatenate(als) if any_alpha else None
+    out = np.empty(max(argb_off, 16), np.uint8)
+    check(L.wp_yuv420_to_argb(n, desc, _np_ptr(y), _np_ptr(u), _np_ptr(v), _np_ptr(al), _np_ptr(out)))
+    return [out[desc[i].argb_off:desc[i].argb_off + 4 * items[i][1] * items[i][2]].copy() for i in range(n)]
+
+
+class Tools:
+    @staticmethod
+    def toArgb(img: Image) -> Image:
+        """Tools.toArgb (Tools.hx:6-48): Argb and Anim pass through unchanged."""
+        if isinstance(img.data, (Argb, Anim)):
+            return img
+        w, h = img.header.width, img.header.height
+        pix = _yuv_to_argb([(img.data, w, h)])[0]
+        hdr = FrameHeader(**vars(img.header))
+        return Image(hdr, Argb(pix, 4 * w))
+
+    @staticmethod
+    def framesToArgb(img: Image) -> List[np.ndarray]:
+        """Per-frame conversion as test/Visual.hx:32-40, 45-89 does: tightly packed ARGB per frame."""
+        if isinstance(img.data, Anim):
+            frames = [(f.data, f.header.width, f.header.height) for f in img.data.frames]
+        else:
+            frames = [(img.data, img.header.width, img.header.height)]
+        out = [None] * len(frames)
+        yuv = [(i, fr) for i, fr in enumerate(frames) if isinstance(fr[0], Yuv420)]
+        if yuv:
+            conv = _yuv_to_argb([fr for _, fr in yuv])
+            for (i, _), c in zip(yuv, conv):
+                out[i] = c
+        for i, (d, w, h) in enumerate(frames):
+            if isinstance(d, Argb):
+                rows = d.pix.reshape(h, d.stride)[:, :4 * w] if d.stride != 4 * w else d.pix.reshape(h, 4 * w)
+                out[i] = np.ascontiguousarray(rows).reshape(-1)
+        return out

@@ -1,0 +1,69 @@
+"""Device-resident batches: packed slabs held in HBM (torch is used only as the allocator / stream
+provider) and thin wrappers over the *_dev entry points of the C ABI."""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import Vp8Frame, check, lib
+from .decoder import LossyBatch
+
+
+def _dev(a: np.ndarray, device):
+    if a.size == 0:
+        a = np.zeros(16, a.dtype)
+    t = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).copy())
+    return t.to(device, non_blocking=False)
+
+
+class DeviceLossyBatch:
+    """A LossyBatch uploaded once; recon / filter / convert run on it with no host traffic."""
+
+    def __init__(self, batch: LossyBatch, device="cuda:0", alpha: np.ndarray = None):
+        self.b = batch
+        self.device = torch.device(device)
+        lib().wp_init(self.device.index or 0)
+        self.frames = _dev(np.frombuffer(bytes(batch.desc), dtype=np.uint8)[:ctypes.sizeof(Vp8Frame) * max(batch.n, 1)], self.device)
+        self.mb = _dev(batch.mb, self.device)
+        self.filt = _dev(batch.filt, self.device)
+        self.coeff = _dev(batch.coeff, self.device)
+        self.y = torch.empty(max(batch.y_bytes, 16), dtype=torch.uint8, device=self.device)
+        self.u = torch.empty(max(batch.u_bytes, 16), dtype=torch.uint8, device=self.device)
+        self.v = torch.empty(max(batch.v_bytes, 16), dtype=torch.uint8, device=self.device)
+        self.argb = torch.empty(max(batch.argb_bytes, 16), dtype=torch.uint8, device=self.device)
+        self.alpha = _dev(alpha, self.device) if alpha is not None else None
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def recon(self):
+        check(lib().wp_vp8_recon_dev(self.b.n, self.b.desc, self.frames.data_ptr(), self.mb.data_ptr(), self.coeff.data_ptr(),
+                                     self.y.data_ptr(), self.u.data_ptr(), self.v.data_ptr(), self._stream()))
+
+    def loopfilter(self):
+        check(lib().wp_vp8_loopfilter_dev(self.b.n, self.b.desc, self.frames.data_ptr(), self.filt.data_ptr(),
+                                          self.y.data_ptr(), self.u.data_ptr(), self.v.data_ptr(), self._stream()))
+
+    def convert(self):
+        check(lib().wp_yuv420_to_argb_dev(self.b.n, self.b.desc, self.frames.data_ptr(), self.y.data_ptr(), self.u.data_ptr(),
+                                          self.v.data_ptr(), self.alpha.data_ptr() if self.alpha is not None else None,
+                                          self.argb.data_ptr(), self._stream()))
+
+    def decode_to_argb(self):
+        check(lib().wp_vp8_decode_to_argb_dev(self.b.n, self.b.desc, self.frames.data_ptr(), self.mb.data_ptr(), self.filt.data_ptr(),
+                                              self.coeff.data_ptr(), self.y.data_ptr(), self.u.data_ptr(), self.v.data_ptr(),
+                                              self.alpha.data_ptr() if self.alpha is not None else None,
+                                              self.argb.data_ptr(), self._stream()))
+
+    # ---- readback helpers (tests) ----
+    def planes(self, i):
+        d = self.b.desc[i]
+        nmb = d.mbw * d.mbh
+        y = self.y[d.y_off:d.y_off + 256 * nmb].cpu().numpy()
+        u = self.u[d.u_off:d.u_off + 64 * nmb].cpu().numpy()
+        v = self.v[d.v_off:d.v_off + 64 * nmb].cpu().numpy()
+        return y, u, v
+
+    def argb_of(self, i):
+        d = self.b.desc[i]
+        return self.argb[d.argb_off:d.argb_off + 4 * d.width * d.height].cpu().numpy()
