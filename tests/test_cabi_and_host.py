@@ -1,0 +1,103 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/webp_amd.h
+declares, and the C++ host side (container walk + entropy decode) reports the same structure and the
+same error strings as the reference for its own fixtures.  No compute entry point is called."""
+import ctypes
+import os
+import re
+import numpy as np
+import pytest
+from conftest import golden_input, ROOT
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "webp_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from webp_amd import _lib
+    L = ctypes.CDLL(_lib.SO_PATH)
+    names = _declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), "missing export: " + n
+
+
+def test_struct_layouts_match_header():
+    from webp_amd._lib import Vp8Frame, Vp8lFrame, Vp8lTransform, AlphaFrame
+    assert ctypes.sizeof(Vp8Frame) == 80 and ctypes.sizeof(Vp8lTransform) == 32
+    assert ctypes.sizeof(Vp8lFrame) == 16 + 4 * 32 + 24 and ctypes.sizeof(AlphaFrame) == 32
+
+
+def test_compute_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from webp_amd import WebPDecoder, WebPError
+    with pytest.raises(WebPError, match="no HIP device"):
+        WebPDecoder.decode(golden_input("1"))
+
+
+@pytest.mark.parametrize("name,kind,w,h,nframes", [
+    ("1", 0, 550, 368, 1), ("3", 0, 1280, 720, 1), ("1ll", 1, 400, 301, 1), ("3ll", 1, 800, 600, 1),
+    ("1a", 2, 46, 32, 108), ("2a", 2, 400, 400, 12), ("a", 0, 300, 300, 1)])
+def test_host_parse_structure(name, kind, w, h, nframes):
+    from webp_amd import parse
+    p = parse(golden_input(name))
+    assert p.kind == kind and len(p.frames) == nframes
+    if name != "2a":
+        assert (p.width, p.height) == (w, h)
+    f = p.frames[0]
+    if f.type == 0:
+        assert f.mbw == (f.width + 15) >> 4 or kind == 2
+        mb = f.buf(0, np.uint32).reshape(-1, 4)
+        assert mb.shape[0] == f.mbw * f.mbh and f.buf(1, np.uint32).size == f.mbw * f.mbh
+        nz = np.array([bin(int(v) & 0x1FFFFFF).count("1") for v in mb[:, 2]])
+        assert f.buf(2, np.int16).size == 16 * nz.sum()                 # one stored block per mask bit
+        assert np.array_equal(mb[:, 3], np.concatenate([[0], np.cumsum(nz)[:-1]]))
+
+
+def test_host_parse_matches_oracle_dimensions_for_all_frames():
+    from oracle import oracle
+    from webp_amd import parse
+    for name in ("1a", "2a"):
+        p = parse(golden_input(name))
+        o = oracle.decode(golden_input(name))
+        assert [(f.width, f.height, f.x, f.y, f.duration) for f in p.frames] == \
+               [(f["width"], f["height"], f["x"], f["y_off"], f["duration"]) for f in o["frames"]]
+
+
+def test_fixture_filter_records():
+    """1.webp: simple filter, level 4; a.webp: normal filter."""
+    from webp_amd import parse
+    f = parse(golden_input("1")).frames[0]
+    assert f.filter_type == 1
+    a = parse(golden_input("a")).frames[0]
+    assert a.filter_type == 2 and a.has_alpha == 1 and a.alpha_is_vp8l == 1
+
+
+@pytest.mark.parametrize("data,msg", [
+    (b"RIFX\x00\x00\x00\x00WEBP", "Missing RIFF chunk header"),
+    (b"RIFF\x02\x00\x00\x00WEBP", "Short chunk data"),
+    (b"RIFF\x04\x00\x00\x00WEBP", "Invalid format: no VP8/VP8L chunk found"),
+    (b"RIFF\x10\x00\x00\x00WEBPVP8L\x04\x00\x00\x00\x2e\x00\x00\x00", "vp8l: invalid header"),
+    (b"RIFF\x16\x00\x00\x00WEBPVP8 \x0a\x00\x00\x00\x00\x00\x00\x9d\x01\x2b\x10\x00\x10\x00", "vp8: invalid format"),
+])
+def test_host_parse_errors_match_reference_strings(data, msg):
+    from webp_amd import parse, WebPError
+    with pytest.raises(WebPError) as e:
+        parse(data)
+    assert msg in str(e.value)
+
+
+def test_truncated_stream_is_null_frame():
+    """A VP8 stream cut short makes the boolean decoder hit EOF: decodeFrame returns null."""
+    from webp_amd import parse, WebPError
+    full = golden_input("1")
+    data = bytearray(full[:len(full) - 2000])
+    data[4:8] = (len(data) - 8).to_bytes(4, "little")
+    data[16:20] = (len(data) - 20).to_bytes(4, "little")
+    with pytest.raises(WebPError) as e:
+        parse(bytes(data))
+    assert e.value.code == -5

@@ -1,0 +1,145 @@
+"""GPU parity of the individual VP8L inverse transforms and the alpha un-filters on seeded random
+inputs (every predictor mode incl. the 14/15 no-ops, cross-colour sign handling, all pixel-packing
+widths, ragged sizes), against the oracle's restatement of Transform.hx / unfilterAlpha."""
+import ctypes
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_chain(cases, swizzle=0):
+    """cases: list of dict(width, height, coded_width, pix, transforms=[(type,bits,old_width,data)])"""
+    from webp_amd._lib import Vp8lFrame, lib, check
+    n = len(cases)
+    desc = (Vp8lFrame * n)()
+    pix, aux = [], []
+    po = ao = oo = 0
+    al = lambda v, a: (v + a - 1) // a * a
+    for i, c in enumerate(cases):
+        d = desc[i]
+        d.width, d.height, d.coded_width = c["width"], c["height"], c["coded_width"]
+        d.n_transforms = len(c["transforms"])
+        d.pix_off, d.out_off, d.tmp_off = po, oo, oo
+        for k, (tt, bits, ow, data) in enumerate(c["transforms"]):
+            t = d.t[k]
+            t.type, t.bits, t.old_width, t.data_off, t.data_len = tt, bits, ow, ao, data.size
+            padded = np.zeros(al(max(data.size, 1), 16), np.uint8); padded[:data.size] = data
+            aux.append(padded); ao += padded.size
+        p = np.zeros(al(c["pix"].size, 256), np.uint8); p[:c["pix"].size] = c["pix"]
+        pix.append(p); po += p.size
+        oo += al(4 * c["width"] * c["height"], 256)
+    pix = np.concatenate(pix); aux = np.concatenate(aux) if aux else np.zeros(16, np.uint8)
+    out = np.zeros(oo, np.uint8)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    check(lib().wp_vp8l_inverse(n, desc, vp(pix), pix.size, vp(aux), aux.size, vp(out), out.size, swizzle))
+    return [out[desc[i].out_off:desc[i].out_off + 4 * cases[i]["width"] * cases[i]["height"]] for i in range(n)]
+
+
+def _tiles(rng, w, h, bits, modes=None):
+    tw, th = (w + (1 << bits) - 1) >> bits, (h + (1 << bits) - 1) >> bits
+    t = rng.integers(0, 256, (th * tw, 4), dtype=np.uint8)
+    if modes is not None:
+        t[:, 1] = (t[:, 1] & 0xF0) | rng.choice(modes, th * tw).astype(np.uint8)
+    return t.reshape(-1)
+
+
+SIZES = [(1, 1), (2, 3), (5, 1), (1, 7), (37, 23), (64, 64), (67, 130), (256, 70), (301, 129)]
+
+
+@pytest.mark.parametrize("bits", [2, 3, 5])
+def test_predictor_all_modes(bits):
+    from oracle import oracle
+    rng = np.random.default_rng(100 + bits)
+    cases, want = [], []
+    for (w, h) in SIZES:
+        for modes in (list(range(16)), [11, 12, 13], [5, 6, 7, 8, 9, 10], [0, 1, 2, 3, 4, 14, 15]):
+            pix = rng.integers(0, 256, 4 * w * h, dtype=np.uint8)
+            if rng.integers(0, 2):            # smooth-ish data drives the clamp / select branches harder
+                pix = (pix // 32).astype(np.uint8)
+            t = _tiles(rng, w, h, bits, modes)
+            cases.append(dict(width=w, height=h, coded_width=w, pix=pix, transforms=[(0, bits, w, t)]))
+            want.append(oracle.inverse_predictor(w, bits, t, pix, h))
+    got = _run_chain(cases)
+    for c, g, e in zip(cases, got, want):
+        assert np.array_equal(g, e), (c["width"], c["height"])
+
+
+def test_cross_color_and_subtract_green():
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    cases, want = [], []
+    for (w, h) in SIZES:
+        for bits in (2, 4):
+            pix = rng.integers(0, 256, 4 * w * h, dtype=np.uint8)
+            t = _tiles(rng, w, h, bits)
+            cases.append(dict(width=w, height=h, coded_width=w, pix=pix, transforms=[(1, bits, w, t)]))
+            want.append(oracle.inverse_cross_color(w, bits, t, pix, h))
+        pix = rng.integers(0, 256, 4 * w * h, dtype=np.uint8)
+        cases.append(dict(width=w, height=h, coded_width=w, pix=pix, transforms=[(2, 0, w, np.zeros(0, np.uint8))]))
+        want.append(oracle.inverse_subtract_green(pix))
+    for g, e in zip(_run_chain(cases), want):
+        assert np.array_equal(g, e)
+
+
+@pytest.mark.parametrize("bits", [0, 1, 2, 3])
+def test_color_indexing(bits):
+    from oracle import oracle
+    rng = np.random.default_rng(9 + bits)
+    cases, want = [], []
+    for (w, h) in SIZES:
+        cw = (w + (1 << bits) - 1) >> bits
+        pix = rng.integers(0, 256, 4 * cw * h, dtype=np.uint8)
+        pal = np.zeros(4 * (1 << (8 >> bits)), np.uint8)
+        pal[:] = rng.integers(0, 256, pal.size, dtype=np.uint8)
+        cases.append(dict(width=w, height=h, coded_width=cw, pix=pix, transforms=[(3, bits, w, pal)]))
+        want.append(oracle.inverse_color_indexing(w, bits, pal, pix, h))
+    for g, e in zip(_run_chain(cases), want):
+        assert np.array_equal(g, e)
+
+
+def test_full_chain_with_swizzle():
+    """predictor + cross-colour + subtract-green in libwebp's bitstream order, then RGBA->ARGB."""
+    from oracle import oracle
+    rng = np.random.default_rng(77)
+    w, h = 203, 131
+    pix = rng.integers(0, 256, 4 * w * h, dtype=np.uint8)
+    tp, tc = _tiles(rng, w, h, 3, list(range(14))), _tiles(rng, w, h, 4)
+    chain = [(2, 0, w, np.zeros(0, np.uint8)), (0, 3, w, tp), (1, 4, w, tc)]       # bitstream order
+    e = oracle.inverse_cross_color(w, 4, tc, pix, h)
+    e = oracle.inverse_predictor(w, 3, tp, e, h)
+    e = oracle.inverse_subtract_green(e).reshape(-1, 4)
+    e = np.ascontiguousarray(e[:, [3, 0, 1, 2]]).reshape(-1)
+    g = _run_chain([dict(width=w, height=h, coded_width=w, pix=pix, transforms=chain)], swizzle=1)[0]
+    assert np.array_equal(g, e)
+
+
+@pytest.mark.parametrize("rgba", [False, True])
+def test_alpha_unfilter_modes(rgba):
+    from oracle import oracle
+    from webp_amd._lib import AlphaFrame, lib, check
+    rng = np.random.default_rng(31)
+    sizes = [(1, 1), (7, 1), (1, 9), (13, 9), (64, 64), (65, 129), (300, 77), (1280, 70)]
+    items = [(w, h, f) for (w, h) in sizes for f in (0, 1, 2, 3)]
+    desc = (AlphaFrame * len(items))()
+    srcs, so, do, want = [], 0, 0, []
+    for i, (w, h, f) in enumerate(items):
+        a = rng.integers(0, 256, w * h, dtype=np.uint8)
+        if f == 3:
+            a = (a // 8).astype(np.uint8)        # small deltas keep the gradient predictor away from pure wrap-around noise
+        want.append(oracle.unfilter_alpha(a, w, f))
+        if rgba:
+            s = rng.integers(0, 256, 4 * w * h, dtype=np.uint8); s[1::4] = a
+        else:
+            s = a
+        d = desc[i]
+        d.width, d.height, d.filter, d.src_is_vp8l_rgba, d.src_off, d.dst_off = w, h, f, int(rgba), so, do
+        pad = (-s.size) % 16
+        srcs.append(np.concatenate([s, np.zeros(pad, np.uint8)])); so += s.size + pad
+        do += (w * h + 15) // 16 * 16
+    src = np.concatenate(srcs); out = np.zeros(do, np.uint8)
+    vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    check(lib().wp_alpha_unfilter(len(items), desc, vp(src), src.size, vp(out), out.size))
+    for i, (w, h, f) in enumerate(items):
+        got = out[desc[i].dst_off:desc[i].dst_off + w * h]
+        assert np.array_equal(got, want[i]), (w, h, f)

@@ -52,6 +52,13 @@ def lib():
     if not os.path.exists(SO_PATH):
         raise RuntimeError("libwebp_amd.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "or `make -C webp_amd/csrc`. There is no CPU fallback." % SO_PATH)
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64; if torch is going to be
+    # used in this process (device memory, streams, torch.distributed) it has to be loaded first so that
+    # this library binds to the same runtime instead of bringing /opt/rocm's copy in beside it.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = ctypes.CDLL(SO_PATH)
     vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     L.wp_init.argtypes = [i32]

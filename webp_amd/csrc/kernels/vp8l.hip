@@ -1,4 +1,450 @@
-// placeholder until the VP8L kernels land (next commit)
+// VP8L inverse transforms and alpha-plane post-processing for a batch of images (gfx950).
+//
+// Replaces vp8l/Transform.hx (inversePredictor :34-188, inverseCrossColor :190-222,
+// inverseSubtractGreen :225-234, inverseColorIndexing :236-281), the driver loop
+// Vp8LDecoder.hx:395-401, the RGBA->ARGB swizzle WebPDecoder.hx:109-123, and the pixel half of
+// readAlpha / unfilterAlpha (WebPDecoder.hx:344-349, 357-411).
+//
+// Pixels are RGBA bytes, i.e. the little-endian dword R | G<<8 | B<<16 | A<<24; all
+// channel arithmetic wraps mod 256 as haxe.io.Bytes.set does.
+//
+// Chain driver (host side, wpk_launch_vp8l): transforms are undone last-read-first.  Pass p handles,
+// for every frame, its transform number n_transforms-1-p.  The per-pixel transforms are pure
+// streaming kernels (one dword per lane, coalesced).  The predictor is a row wavefront: pixel (x,y)
+// needs L, TL, T, TR, so row y may trail row y-1 by a few pixels; one wavefront owns 64 rows
+// (lane = row), rows are skewed by two 4-pixel chunks and exchange their finished chunks with DPP-free
+// lane shuffles; 64-row bands are pipelined across the wavefronts of a workgroup through an LDS
+// progress word, the boundary row going through memory (workgroup-scope release/acquire).
 #include "wp_device.h"
-extern "C" int wpk_launch_vp8l(int, const wp_vp8l_frame*, const wp_vp8l_frame*, uint8_t*, const uint8_t*, uint8_t*, uint8_t*, int, hipStream_t) { return int(hipErrorNotSupported); }
-extern "C" int wpk_launch_alpha(int, const wp_alpha_frame*, const wp_alpha_frame*, const uint8_t*, uint8_t*, hipStream_t) { return int(hipErrorNotSupported); }
+#include <algorithm>
+
+namespace wpk {
+
+__device__ __forceinline__ int n_tiles(int dim, int bits) { return (dim + (1 << bits) - 1) >> bits; }   // Transform.hx:23-25
+
+// Where a frame's pixels live before inverse pass `p`: the decodePix slab until a colour-indexing
+// transform with pixel packing (bits > 0) has expanded them into the scratch slab.
+struct Loc { bool in_tmp; int width; };
+__device__ __forceinline__ Loc locate(const wp_vp8l_frame& fr, int idx /* transform about to be undone */) {
+    Loc l{false, fr.coded_width};
+    for (int j = fr.n_transforms - 1; j > idx; --j)
+        if (fr.t[j].type == 3) { l.width = fr.t[j].old_width; if (fr.t[j].bits > 0) l.in_tmp = true; }
+    return l;
+}
+
+// per-byte wrapping add of two packed pixels
+__device__ __forceinline__ uint32_t add_px(uint32_t a, uint32_t b) {
+    return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
+}
+// per-byte floor((a + b) / 2)  (Transform.hx:283-285 avg2)
+__device__ __forceinline__ uint32_t avg_px(uint32_t a, uint32_t b) { return (a & b) + (((a ^ b) & 0xfefefefeu) >> 1); }
+
+// ---------------------------------------------------------------- streaming transforms
+__global__ __launch_bounds__(256)
+void vp8l_subtract_green_kernel(const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp) {
+    const wp_vp8l_frame fr = frames[blockIdx.y];
+    const int idx = fr.n_transforms - 1 - pass;
+    if (idx < 0 || fr.t[idx].type != 2) return;
+    const Loc loc = locate(fr, idx);
+    uint32_t* p = reinterpret_cast<uint32_t*>(loc.in_tmp ? tmp + fr.tmp_off : pix + fr.pix_off);
+    const long long total = (long long)loc.width * fr.height;          // the reference walks the whole buffer (:227)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t v = p[i];
+        const uint32_t g = (v >> 8) & 0xff;
+        p[i] = add_px(v, g | (g << 16));                               // R += G, B += G
+    }
+}
+
+__device__ __forceinline__ int s8(uint32_t v) { return int(int8_t(v & 0xff)); }
+
+__global__ __launch_bounds__(256)
+void vp8l_cross_color_kernel(const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp, const uint8_t* __restrict__ aux) {
+    const wp_vp8l_frame fr = frames[blockIdx.y];
+    const int idx = fr.n_transforms - 1 - pass;
+    if (idx < 0 || fr.t[idx].type != 1) return;
+    const Loc loc = locate(fr, idx);
+    uint32_t* p = reinterpret_cast<uint32_t*>(loc.in_tmp ? tmp + fr.tmp_off : pix + fr.pix_off);
+    const int w = fr.t[idx].old_width, bits = fr.t[idx].bits;
+    const int tpr = n_tiles(w, bits);
+    const uint32_t* tiles = reinterpret_cast<const uint32_t*>(aux + fr.t[idx].data_off);
+    const long long total = (long long)w * fr.height;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int y = int(i / w), x = int(i - (long long)y * w);
+        const uint32_t t = tiles[(y >> bits) * tpr + (x >> bits)];
+        const int r2b = s8(t), g2b = s8(t >> 8), g2r = s8(t >> 16);       // Transform.hx:202-204
+        const uint32_t v = p[i];
+        const int g = s8(v >> 8);
+        uint32_t red = (v & 0xff) + (uint32_t(g2r * g) >> 5);              // unsigned >>> 5, low 8 bits kept (Q10)
+        uint32_t blue = ((v >> 16) & 0xff) + (uint32_t(g2b * g) >> 5);
+        blue = (blue & 0xff) + (uint32_t(r2b * s8(red)) >> 5);
+        p[i] = (v & 0xff00ff00u) | (red & 0xff) | ((blue & 0xff) << 16);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void vp8l_color_indexing_kernel(const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp, const uint8_t* __restrict__ aux) {
+    const wp_vp8l_frame fr = frames[blockIdx.y];
+    const int idx = fr.n_transforms - 1 - pass;
+    if (idx < 0 || fr.t[idx].type != 3) return;
+    const Loc loc = locate(fr, idx);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(loc.in_tmp ? tmp + fr.tmp_off : pix + fr.pix_off);
+    const int w = fr.t[idx].old_width, bits = fr.t[idx].bits;
+    const uint32_t* palette = reinterpret_cast<const uint32_t*>(aux + fr.t[idx].data_off);
+    if (bits == 0) {                                                        // in place, whole buffer (:237-248)
+        uint32_t* p = const_cast<uint32_t*>(src);
+        const long long total = (long long)loc.width * fr.height;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+            p[i] = palette[(p[i] >> 8) & 0xff];
+        return;
+    }
+    uint32_t* dst = reinterpret_cast<uint32_t*>(tmp + fr.tmp_off);           // new 4*oldWidth*h buffer (:261)
+    const int pw = loc.width;                                                // packed row length = nTiles(oldWidth, bits)
+    const int bpp = 8 >> bits, xmask = (1 << bits) - 1;
+    const uint32_t vmask = (1u << bpp) - 1u;
+    const long long total = (long long)w * fr.height;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int y = int(i / w), x = int(i - (long long)y * w);
+        const uint32_t g = (src[(long long)y * pw + (x >> bits)] >> 8) & 0xff;
+        dst[i] = palette[(g >> ((x & xmask) * bpp)) & vmask];
+    }
+}
+
+// final copy into the result slab, with the RGBA -> ARGB byte rotation of WebPDecoder.hx:109-123
+__global__ __launch_bounds__(256)
+void vp8l_finish_kernel(const wp_vp8l_frame* __restrict__ frames, const uint8_t* pix, const uint8_t* tmp, uint8_t* out, int swizzle) {
+    const wp_vp8l_frame fr = frames[blockIdx.y];
+    const Loc loc = locate(fr, -1);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(loc.in_tmp ? tmp + fr.tmp_off : pix + fr.pix_off);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out + fr.out_off);
+    const long long total = (long long)fr.width * fr.height;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t v = src[i];
+        dst[i] = swizzle ? ((v << 8) | (v >> 24)) : v;
+    }
+}
+
+// ---------------------------------------------------------------- predictor (row wavefront)
+__device__ __forceinline__ int clamp255i(int v) { return clampi(v, 0, 255); }
+
+// One predicted pixel (Transform.hx:78-182).  Modes 14 and 15 have no case: nothing is added.
+__device__ __forceinline__ uint32_t predict_px(int mode, uint32_t L, uint32_t T, uint32_t TL, uint32_t TR) {
+    switch (mode) {
+    case 0: return 0xff000000u;
+    case 1: return L;
+    case 2: return T;
+    case 3: return TR;
+    case 4: return TL;
+    case 5: return avg_px(avg_px(L, TR), T);
+    case 6: return avg_px(L, TL);
+    case 7: return avg_px(L, T);
+    case 8: return avg_px(TL, T);
+    case 9: return avg_px(T, TR);
+    case 10: return avg_px(avg_px(L, TL), avg_px(T, TR));
+    case 11: {   // select: l = sum|TL - T|, t = sum|TL - L|; L if l < t else T
+        const uint32_t l = __builtin_amdgcn_sad_u8(TL, T, 0u), t = __builtin_amdgcn_sad_u8(TL, L, 0u);
+        return l < t ? L : T; }
+    case 12: {   // clampAddSubtractFull(L, T, TL) per channel
+        uint32_t r = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int a = (L >> (8 * k)) & 0xff, b = (T >> (8 * k)) & 0xff, c = (TL >> (8 * k)) & 0xff;
+            r |= uint32_t(clamp255i(a + b - c)) << (8 * k);
+        }
+        return r; }
+    case 13: {   // clampAddSubtractHalf(avg2(L, T), TL): a + trunc((a - b) / 2)  (Q10: C-style division)
+        const uint32_t av = avg_px(L, T);
+        uint32_t r = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int a = (av >> (8 * k)) & 0xff, b = (TL >> (8 * k)) & 0xff;
+            r |= uint32_t(clamp255i(a + (a - b) / 2)) << (8 * k);
+        }
+        return r; }
+    default: return 0u;
+    }
+}
+
+struct __attribute__((aligned(4))) Px4 { uint32_t v[4]; };
+constexpr uint32_t kPredSeqShift = 15;      // progress word = (band sequence << 15) | pixels finished in the band's last row
+constexpr int kPredRows = 64;
+
+__global__ __launch_bounds__(kWavesPerWG * kWave)
+void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp,
+                           const uint8_t* __restrict__ aux) {
+    __shared__ uint32_t progress[kWavesPerWG];
+    const int wave = threadIdx.x >> 6;
+    const int r = threadIdx.x & 63;                 // row within the band
+    if (threadIdx.x < kWavesPerWG) progress[threadIdx.x] = 0;
+    __syncthreads();
+
+    uint32_t seq = 1;
+    for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        const wp_vp8l_frame fr = frames[f];
+        const int idx = fr.n_transforms - 1 - pass;
+        if (idx < 0 || fr.t[idx].type != 0) continue;
+        const Loc loc = locate(fr, idx);
+        uint32_t* base = reinterpret_cast<uint32_t*>(loc.in_tmp ? tmp + fr.tmp_off : pix + fr.pix_off);
+        const int w = fr.t[idx].old_width, h = fr.height, bits = fr.t[idx].bits;
+        if (w == 0 || h == 0) continue;
+        const int tpr = n_tiles(w, bits);
+        const uint8_t* tiles = aux + fr.t[idx].data_off;
+        const int n_bands = (h + kPredRows - 1) / kPredRows;
+        const int n_chunks = (w + 3) >> 2;
+
+        for (int band = 0; band < n_bands; ++band) {
+            const uint32_t q = seq + uint32_t(band);
+            if (int(q % kWavesPerWG) != wave) continue;
+            const int y = band * kPredRows + r;
+            const bool row_ok = y < h;
+            const bool has_above = band > 0, has_below = band + 1 < n_bands;
+            const int prev_wave = (wave + kWavesPerWG - 1) % kWavesPerWG;
+            const int rows_here = min(kPredRows, h - band * kPredRows);
+            const int n_steps = n_chunks + 2 * (rows_here - 1);
+            uint32_t* row = base + (long long)(row_ok ? y : 0) * w;
+            const uint32_t* above_row = base + (long long)(y > 0 ? y - 1 : 0) * w;
+            const uint8_t* tile_row = tiles + 4 * ((row_ok ? y : 0) >> bits) * tpr;
+
+            uint32_t P1[4] = {0, 0, 0, 0};          // my outputs of the previous chunk (what the row below fetches)
+            uint32_t T4[4] = {0, 0, 0, 0};          // row above, pixels of the current chunk
+            uint32_t Tn[4] = {0, 0, 0, 0};          // row above, next chunk (fetched one step early)
+            uint32_t TLfirst = 0, Lpx = 0, first_px = 0;
+            uint32_t avail = 0;                     // pixels of the row above known to be finished (band boundary)
+
+            for (int c = 0; c < n_steps; ++c) {
+                const int k = c - 2 * r;
+                const bool act = row_ok && k >= 0 && k < n_chunks;
+                // ---- fetch chunk k+1 of the row above: from lane r-1 (its previous chunk), or from memory for the band's first row
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { T4[j] = Tn[j]; Tn[j] = __shfl_up(P1[j], 1); }
+                if (has_above && c + 1 < n_chunks + 1) {
+                    // lane 0 is about to need pixels up to 4*(c+2)-1 of row y-1
+                    const uint32_t need = uint32_t(min(4 * (c + 2), w));
+                    if (avail < need) {
+                        const uint32_t target = ((q - 1) << kPredSeqShift) | need;
+                        uint32_t v;
+                        while ((v = __hip_atomic_load(&progress[prev_wave], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+                            __builtin_amdgcn_s_sleep(1);
+                        avail = (v >> kPredSeqShift) == (q - 1) ? (v & ((1u << kPredSeqShift) - 1u)) : uint32_t(w);
+                    }
+                    if (r == 0) {
+                        const int x0 = 4 * (c + 1);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) Tn[j] = (x0 + j < w) ? above_row[x0 + j] : 0u;
+                        if (c == 0) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) T4[j] = (j < w) ? above_row[j] : 0u;
+                        }
+                    }
+                }
+                if (act) {
+                    const int x0 = 4 * k;
+                    uint32_t in[4], out[4];
+                    if (x0 + 4 <= w) {
+                        const Px4 v = *reinterpret_cast<const Px4*>(row + x0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) in[j] = v.v[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) in[j] = (x0 + j < w) ? row[x0 + j] : 0u;
+                    }
+                    const int tile_mode = tile_row[4 * (x0 >> bits) + 1] & 15;   // a 4-pixel chunk never straddles a tile (bits >= 2)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int x = x0 + j;
+                        uint32_t pred;
+                        if (y == 0) pred = x == 0 ? 0xff000000u : Lpx;            // first row: black / L (:40-53)
+                        else if (x == 0) pred = T4[0];                            // first column: T (:61-64)
+                        else {
+                            const uint32_t TL = j ? T4[j - 1] : TLfirst;
+                            uint32_t TR = j < 3 ? T4[j + 1] : Tn[0];
+                            if (x == w - 1) TR = first_px;                        // linear addressing: top+4 is the row's own first pixel
+                            pred = predict_px(tile_mode, Lpx, T4[j], TL, TR);
+                        }
+                        out[j] = add_px(in[j], pred);
+                        if (x < w) Lpx = out[j];
+                        if (x == 0) first_px = out[j];
+                    }
+                    if (x0 + 4 <= w) {
+                        Px4 v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v.v[j] = out[j];
+                        *reinterpret_cast<Px4*>(row + x0) = v;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (x0 + j < w) row[x0 + j] = out[j];
+                    }
+                    TLfirst = T4[3];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) P1[j] = out[j];
+                }
+                if (has_below) {
+                    const int k_last = c - 2 * (kPredRows - 1);
+                    if (k_last >= 0 && ((k_last & 3) == 3 || k_last == n_chunks - 1))
+                        publish_progress(&progress[wave], (q << kPredSeqShift) | uint32_t(min(4 * (k_last + 1), w)));
+                }
+            }
+        }
+        seq += uint32_t(n_bands);
+    }
+}
+
+// ---------------------------------------------------------------- alpha plane (WebPDecoder.hx:311-411)
+__device__ __forceinline__ uint32_t alpha_src(const uint8_t* src, bool rgba, long long i) { return rgba ? src[4 * i + 1] : src[i]; }
+
+// filter 0: copy / green extraction.  filters 1-3, stage 1: first row is a running sum along x and
+// the first column of the other rows a running sum along y (:364-370, :380-384, :389-396).
+__global__ __launch_bounds__(256)
+void alpha_copy_kernel(const wp_alpha_frame* __restrict__ frames, const uint8_t* __restrict__ src, uint8_t* alpha) {
+    const wp_alpha_frame fr = frames[blockIdx.y];
+    const uint8_t* s = src + fr.src_off;
+    uint8_t* d = alpha + fr.dst_off;
+    const long long total = (long long)fr.width * fr.height;
+    const bool rgba = fr.src_is_vp8l_rgba != 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        d[i] = uint8_t(alpha_src(s, rgba, i));
+}
+
+// vertical filter, stage 1: running sum along row 0 (one wavefront per frame, 64 bytes per round).
+__global__ __launch_bounds__(64)
+void alpha_row0_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* alpha) {
+    const wp_alpha_frame fr = frames[blockIdx.x];
+    if (fr.filter != 2) return;
+    uint8_t* a = alpha + fr.dst_off;
+    const int lane = threadIdx.x;
+    uint32_t carry = 0;
+    for (int xb = 0; xb < fr.width; xb += 64) {
+        const int x = xb + lane;
+        uint32_t v = x < fr.width ? a[x] : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d); if (lane >= d) v += t; }
+        v = (v + carry) & 0xff;
+        if (x < fr.width) a[x] = uint8_t(v);
+        carry = __shfl(v, 63);
+    }
+}
+// vertical filter, stage 2: running sum down every column (:383-385); thread = column, coalesced rows.
+__global__ __launch_bounds__(256)
+void alpha_columns_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* alpha) {
+    const wp_alpha_frame fr = frames[blockIdx.y];
+    if (fr.filter != 2) return;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= fr.width) return;
+    uint8_t* a = alpha + fr.dst_off + x;
+    const int w = fr.width, h = fr.height;
+    uint32_t acc = a[0];
+    int y = 1;
+    for (; y + 8 <= h; y += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = a[(long long)(y + k) * w];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { acc = (acc + v[k]) & 0xff; a[(long long)(y + k) * w] = uint8_t(acc); }
+    }
+    for (; y < h; ++y) { acc = (acc + a[(long long)y * w]) & 0xff; a[(long long)y * w] = uint8_t(acc); }
+}
+
+// horizontal (1) and gradient (3) filters: one wavefront per frame, sequential over 64-row bands,
+// lane = row, rows skewed by one pixel (row r handles x = s - r): the row above has then just
+// produced its pixel x.  The band's first row reads the previous band's last row from memory in
+// 64-byte blocks fetched one block ahead.
+__global__ __launch_bounds__(64)
+void alpha_unfilter_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* alpha) {
+    const wp_alpha_frame fr = frames[blockIdx.x];
+    const int w = fr.width, h = fr.height, filter = fr.filter;
+    if (filter != 1 && filter != 3) return;
+    uint8_t* a = alpha + fr.dst_off;
+    const int lane = threadIdx.x;
+    for (int y0 = 0; y0 < h; y0 += 64) {
+        const int y = y0 + lane;
+        const bool row_ok = y < h;
+        const int rows_here = min(64, h - y0);
+        uint8_t* row = a + (long long)(row_ok ? y : 0) * w;
+        const uint8_t* above = a + (long long)(y0 > 0 ? y0 - 1 : 0) * w;      // last row of the previous band (own stores)
+        uint32_t cur = 0, up_prev = 0;
+        uint32_t abuf = (y0 > 0 && lane < w) ? above[lane] : 0u;
+        uint32_t anext = (y0 > 0 && 64 + lane < w) ? above[64 + lane] : 0u;
+        const int n_steps = w + rows_here - 1;
+        for (int s = 0; s < n_steps; ++s) {
+            const int x = s - lane;
+            uint32_t up = __shfl_up(cur, 1);                                   // row above at column x (lane-1 produced it last step)
+            const uint32_t up0 = __shfl(abuf, s & 63);                         // the same for the band's first row
+            if (lane == 0) up = up0;
+            if ((s & 63) == 63) {
+                abuf = anext;
+                const int nx = s + 1 + 64 + lane;
+                anext = (y0 > 0 && nx < w) ? above[nx] : 0u;
+            }
+            if (row_ok && x >= 0 && x < w) {
+                const uint32_t v = row[x];
+                uint32_t pred;
+                if (x == 0) pred = y == 0 ? 0u : up;                            // first column: vertical (:370, :396)
+                else if (y == 0 || filter == 1) pred = cur;                     // first row / horizontal: L
+                else pred = uint32_t(clampi(int(cur) + int(up) - int(up_prev), 0, 255));   // gradient (:399-405)
+                cur = (v + pred) & 0xff;
+                row[x] = uint8_t(cur);
+                up_prev = up;
+            }
+        }
+        // this band's last row must be complete before lane-wide reads of it in the next band
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+}  // namespace wpk
+
+namespace {
+int grid_for(long long items, int n_frames) {
+    long long g = (items + 255) / 256;
+    const long long cap = std::max(8LL, 16384LL / std::max(1, n_frames));
+    return int(std::max(1LL, std::min(g, cap)));
+}
+}  // namespace
+
+extern "C" int wpk_launch_vp8l(int n, const wp_vp8l_frame* fh, const wp_vp8l_frame* fd, uint8_t* d_pix, const uint8_t* d_aux,
+                               uint8_t* d_tmp, uint8_t* d_out, int swizzle, hipStream_t stream) {
+    using namespace wpk;
+    long long max_px = 1;
+    for (int i = 0; i < n; ++i) max_px = std::max(max_px, (long long)fh[i].width * fh[i].height);
+    for (int first = 0; first < n; first += 65535) {
+        const int cnt = std::min(65535, n - first);
+        const wp_vp8l_frame* fdc = fd + first;
+        const int gx = grid_for(max_px, cnt);
+        for (int pass = 0; pass < WP_VP8L_MAX_TRANSFORMS; ++pass) {
+            bool have[4] = {false, false, false, false};
+            for (int i = first; i < first + cnt; ++i) {
+                const int idx = fh[i].n_transforms - 1 - pass;
+                if (idx >= 0) have[fh[i].t[idx].type] = true;
+            }
+            if (have[0])
+                hipLaunchKernelGGL(vp8l_predictor_kernel, dim3(std::min(cnt, 1024)), dim3(kWavesPerWG * kWave), 0, stream,
+                                   cnt, fdc, pass, d_pix, d_tmp, d_aux);
+            if (have[1]) hipLaunchKernelGGL(vp8l_cross_color_kernel, dim3(gx, cnt), dim3(256), 0, stream, fdc, pass, d_pix, d_tmp, d_aux);
+            if (have[2]) hipLaunchKernelGGL(vp8l_subtract_green_kernel, dim3(gx, cnt), dim3(256), 0, stream, fdc, pass, d_pix, d_tmp);
+            if (have[3]) hipLaunchKernelGGL(vp8l_color_indexing_kernel, dim3(gx, cnt), dim3(256), 0, stream, fdc, pass, d_pix, d_tmp, d_aux);
+        }
+        hipLaunchKernelGGL(vp8l_finish_kernel, dim3(gx, cnt), dim3(256), 0, stream, fdc, d_pix, d_tmp, d_out, swizzle);
+    }
+    return int(hipGetLastError());
+}
+
+extern "C" int wpk_launch_alpha(int n, const wp_alpha_frame* fh, const wp_alpha_frame* fd, const uint8_t* d_src, uint8_t* d_alpha,
+                                hipStream_t stream) {
+    using namespace wpk;
+    long long max_px = 1;
+    for (int i = 0; i < n; ++i) { max_px = std::max(max_px, (long long)fh[i].width * fh[i].height); }
+    for (int first = 0; first < n; first += 65535) {
+        const int cnt = std::min(65535, n - first);
+        hipLaunchKernelGGL(alpha_copy_kernel, dim3(grid_for(max_px, cnt), cnt), dim3(256), 0, stream, fd + first, d_src, d_alpha);
+    }
+    bool f2 = false, f13 = false;
+    int max_w = 1;
+    for (int i = 0; i < n; ++i) { f2 = f2 || fh[i].filter == 2; f13 = f13 || fh[i].filter == 1 || fh[i].filter == 3; max_w = std::max(max_w, fh[i].width); }
+    if (f2) {
+        hipLaunchKernelGGL(alpha_row0_kernel, dim3(n), dim3(64), 0, stream, fd, d_alpha);
+        for (int first = 0; first < n; first += 65535)
+            hipLaunchKernelGGL(alpha_columns_kernel, dim3((max_w + 255) / 256, std::min(65535, n - first)), dim3(256), 0, stream, fd + first, d_alpha);
+    }
+    if (f13) hipLaunchKernelGGL(alpha_unfilter_kernel, dim3(n), dim3(64), 0, stream, fd, d_alpha);
+    return int(hipGetLastError());
+}
