@@ -51,7 +51,7 @@ def cpu_baseline(paths, budget_s=12.0):
         n += 1
     dt = time.time() - t0
     return {"value": px / dt / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
-            "sample": "%d x 1920x1080 lossy (bench_data/lossy1080_q75_*.webp cycled), decode+toArgb, %.1f s, "
+            "sample": "%d x 1920x1080 lossy (bench_data/lossy1080_*.webp cycled), decode+toArgb, %.1f s, "
                       "reference Haxe toolchain unavailable on the box: timed the C restatement (oracle/)" % (n, dt)}
 
 
@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--images", type=int, default=1024, help="images per GPU")
-    ap.add_argument("--pattern", default="lossy1080_q75_[0-9].webp")
+    ap.add_argument("--pattern", default="lossy1080_*.webp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -133,7 +133,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32/u8 (+f64 colour conversion)",
             "data": "synthetic",
-            "config": {"workload": "%d x 1920x1080 VP8 lossy (libwebp q75 m4, normal loop filter) per GPU: recon + loop filter + "
+            "config": {"workload": "%d x 1920x1080 VP8 lossy (libwebp: 8 x q75 m4 normal filter + q90 + q50 sharp3 + simple-filter variant) per GPU: recon + loop filter + "
                                    "YUV420->ARGB, inputs resident in HBM" % args.images,
                        "images_per_gpu": args.images, "distinct_streams": len(paths), "sharding": "images across ranks, no collective",
                        "macroblocks_per_gpu": n_mb, "coeff_blocks_per_mb": round(batch.n_coeff_blocks / max(n_mb, 1), 3),

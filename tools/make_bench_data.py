@@ -16,7 +16,7 @@ def synth(w, h, seed, block_sigma=18.0, px_sigma=6.0):
     noise = rng.normal(0, px_sigma, (h, w, 3))
     return np.clip(base + blocky + noise, 0, 255).astype(np.uint8)
 
-def enc(arr, name, quality=75, method=4, filter_type=1, strength=-1, sharp=0, lossless=0, alpha_q=100, partitions=0, segments=4):
+def enc(arr, name, quality=75, method=4, filter_type=1, strength=60, sharp=0, lossless=0, alpha_q=100, partitions=0, segments=4):
     h, w, ch = arr.shape
     raw = "/tmp/_enc_in.raw"
     arr.tofile(raw)
