@@ -20,6 +20,7 @@ namespace wpk {
 struct ReconTile {              // bytes; row pitch 32 so that 4-pixel groups are dword aligned
     uint8_t y[17][32];          // row 0: [3] corner, [4..19] top, [20..23] top-right; rows 1..16: [3] left, [4..19] pixels
     uint8_t c[9][32];           // Cb at cols 3 | 4..11, Cr at cols 19 | 20..27; row 0 is the top border
+    uint8_t pad[32];            // 864 B = 216 dwords: the four groups' tiles start 24 banks apart (no 2-way conflicts)
 };
 struct ReconWaveLds {
     ReconTile tile[kBandRows];
@@ -88,20 +89,18 @@ __device__ __forceinline__ void load_block(const int16_t* p, int (&c)[16]) {
     for (int i = 0; i < 8; ++i) { c[2 * i] = int(int16_t(w[i] & 0xffff)); c[2 * i + 1] = int(w[i]) >> 16; }
 }
 
-// inverseWHT16 (Vp8Decoder.hx:960-989): returns the DC that lands in luma block n = 4*i + k,
-// computed in int32 without truncation.
-__device__ __forceinline__ int wht_dc(const int (&c)[16], int n) {
-    const int i = n >> 2, k = n & 3;
-    int mm[4];      // m[4*i + j], j = 0..3
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int a0 = c[j] + c[12 + j], a1 = c[4 + j] + c[8 + j], a2 = c[4 + j] - c[8 + j], a3 = c[j] - c[12 + j];
-        mm[j] = i == 0 ? a0 + a1 : i == 1 ? a3 + a2 : i == 2 ? a0 - a1 : a3 - a2;
-    }
-    const int dc = mm[0] + 3;
-    const int a0 = dc + mm[3], a1 = mm[1] + mm[2], a2 = mm[1] - mm[2], a3 = dc - mm[3];
-    const int v = k == 0 ? a0 + a1 : k == 1 ? a3 + a2 : k == 2 ? a0 - a1 : a3 - a2;
-    return v >> 3;
+// inverseWHT16 (Vp8Decoder.hx:960-989) spread over the 16 lanes of a group: lane (r, c) holds input
+// coefficient 4r+c and ends up with the DC of luma block 4r+c.  int32 throughout, no truncation.
+__device__ __forceinline__ int wht_dc_lanes(int v, int l) {
+    const int r = l >> 2, c = l & 3;
+    const int i0 = __shfl(v, c, 16), i1 = __shfl(v, 4 + c, 16), i2 = __shfl(v, 8 + c, 16), i3 = __shfl(v, 12 + c, 16);
+    const int a0 = i0 + i3, a1 = i1 + i2, a2 = i1 - i2, a3 = i0 - i3;
+    const int m = r == 0 ? a0 + a1 : r == 1 ? a3 + a2 : r == 2 ? a0 - a1 : a3 - a2;      // m[4r + c]
+    const int m0 = __shfl(m, 4 * r, 16), m1 = __shfl(m, 4 * r + 1, 16), m2 = __shfl(m, 4 * r + 2, 16), m3 = __shfl(m, 4 * r + 3, 16);
+    const int dc = m0 + 3;
+    const int b0 = dc + m3, b1 = m1 + m2, b2 = m1 - m2, b3 = dc - m3;
+    const int o = c == 0 ? b0 + b1 : c == 1 ? b3 + b2 : c == 2 ? b0 - b1 : b3 - b2;
+    return o >> 3;
 }
 
 // The ten 4x4 luma predictors (PredFunc.hx:118-418).  top8 = the 8 pixels above (4 above the
@@ -255,26 +254,37 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
             const int rows_here = min(kBandRows, mbh - band * kBandRows);
             const int n_steps = mbw + 2 * (rows_here - 1);
 
+            // The MB record is fetched one step ahead so that the coefficient addresses are known as soon as a
+            // step starts (two dependent global round trips would otherwise sit on every step's critical path).
+            const uint4* mb_row = mb + size_t(fr.mb_base) + size_t(row_ok ? y : 0) * mbw;
+            uint4 rec_next = make_uint4(0, 0, 0, 0);
+            if (row_ok && g == 0) rec_next = mb_row[0];
+            settle(rec_next);
+            uint32_t pending_publish = 0;
+
             for (int s = 0; s < n_steps; ++s) {
                 const int x = s - 2 * g;
                 const bool act = row_ok && x >= 0 && x < mbw;
+                const uint4 rec = act ? rec_next : make_uint4(0, 0, 0, 0);
+                if (row_ok && x + 1 >= 0 && x + 1 < mbw) rec_next = mb_row[x + 1];
 
-                // ---- top context of group 0 comes from the band above, through the output planes ----
+                // ---- top context of group 0 comes from the band above, through the output planes: issue the
+                //      loads now, park them in the LDS ring after the residuals have been computed ----
+                uint32_t top_a = 0, top_b = 0;
+                const bool fetch_top = has_above && s < mbw && g == 0 && l < 8;
                 if (has_above && s < mbw) {
                     wait_progress(&progress[prev_wave], ((q - 1) << kSeqShift) | uint32_t(min(s + 2, mbw)));
-                    if (g == 0 && l < 8) {
+                    if (fetch_top) {
                         const uint8_t* src0 = l < 4 ? Y + size_t(16 * y - 1) * ystride + 4 * l
                                             : l < 6 ? U + size_t(8 * y - 1) * cstride + 4 * (l - 4)
                                                     : V + size_t(8 * y - 1) * cstride + 4 * (l - 6);
                         const int colbytes = l < 4 ? 16 : 8;
-                        if (s == 0) lds.ring[0][0][l] = *reinterpret_cast<const uint32_t*>(src0);
-                        if (s + 1 < mbw) lds.ring[0][(s + 1) & 3][l] = *reinterpret_cast<const uint32_t*>(src0 + size_t(s + 1) * colbytes);
+                        if (s == 0) top_a = *reinterpret_cast<const uint32_t*>(src0);
+                        if (s + 1 < mbw) top_b = *reinterpret_cast<const uint32_t*>(src0 + size_t(s + 1) * colbytes);
                     }
                 }
 
-                // ---- macroblock record and residuals (independent of the neighbours) ----
-                uint4 rec = make_uint4(0, 0, 0, 0);
-                if (act) rec = mb[size_t(fr.mb_base) + size_t(y) * mbw + x];
+                // ---- residuals (independent of the neighbours) ----
                 const uint32_t w2 = rec.z;
                 const bool i16 = (w2 >> WP_MB_I16_BIT) & 1;
                 const int has_wht = (w2 >> WP_MB_WHT_BIT) & 1;
@@ -288,11 +298,10 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                     const bool present = act && ((w2 >> l) & 1);
                     if (present) load_block(cbase + size_t(has_wht + __popc(w2 & ((1u << l) - 1u))) * 16, c);
                     int dc16 = 0;
-                    if (act && i16 && has_wht) {
-                        int wc[16];
-                        load_block(cbase, wc);
-                        dc16 = wht_dc(wc, l);
-                        c[0] = dc16;
+                    if (__builtin_amdgcn_ballot_w64(act && has_wht) != 0) {
+                        const int wv = (act && has_wht) ? int(cbase[l]) : 0;
+                        dc16 = wht_dc_lanes(wv, l);
+                        if (act && has_wht) c[0] = dc16; else dc16 = 0;
                     }
                     if (present || dc16 != 0) idct_residual(c, ev, od);
                 }
@@ -304,6 +313,11 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                     load_block(cbase + size_t(has_wht + __popc(w2 & ((1u << cn) - 1u))) * 16, c);
                     idct_residual(c, cev, cod);
                 }
+                if (fetch_top) {
+                    if (s == 0) lds.ring[0][0][l] = top_a;
+                    if (s + 1 < mbw) lds.ring[0][(s + 1) & 3][l] = top_b;
+                }
+                __builtin_amdgcn_wave_barrier();
 
                 uint32_t px[4] = {0, 0, 0, 0}, cpx[4] = {0, 0, 0, 0};
                 if (act) {
@@ -406,8 +420,19 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                             tile32(T.c[4 * cj + 1 + r], cb + 4 * ci) = cpx[r];
                         }
                     }
-
+                }
+                // ---- tell the band below how far this band's last row has got.  The value published here is the
+                //      one of the PREVIOUS step: its stores were issued a whole step ago, so the release fence
+                //      (s_waitcnt vmcnt(0)) does not stall on store acknowledgements ----
+                settle(rec_next);        // the prefetch has had the whole step to land; wait for it before this step's stores go out
+                if (has_below) {
+                    if (pending_publish) publish_progress(&progress[wave], pending_publish);
+                    const int done = s - 2 * (kBandRows - 1) + 1;
+                    pending_publish = done >= 1 ? ((q << kSeqShift) | uint32_t(done)) : 0u;
+                }
+                if (act) {
                     // ---- write back (Vp8Decoder.hx:812-821) ----
+                    const int plane = l >> 3;
                     uint8_t* yd = Y + size_t(16 * y + 4 * bj) * ystride + 16 * x + 4 * bi;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) *reinterpret_cast<uint32_t*>(yd + size_t(r) * ystride) = px[r];
@@ -426,12 +451,8 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                                              : tile32(T.c[8], 20 + 4 * (l - 6));
                     lds.ring[g + 1][x & 3][l] = v;
                 }
-                // ---- tell the band below how far this band's last row has got ----
-                if (has_below) {
-                    const int done = s - 2 * (kBandRows - 1) + 1;
-                    if (done >= 1) publish_progress(&progress[wave], (q << kSeqShift) | uint32_t(done));
-                }
             }
+            if (has_below && pending_publish) publish_progress(&progress[wave], pending_publish);
         }
         seq += uint32_t(n_bands);
     }

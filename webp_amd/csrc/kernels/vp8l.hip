@@ -222,8 +222,9 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                     if (avail < need) {
                         const uint32_t target = ((q - 1) << kPredSeqShift) | need;
                         uint32_t v;
-                        while ((v = __hip_atomic_load(&progress[prev_wave], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+                        while ((v = __hip_atomic_load(&progress[prev_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
                             __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         avail = (v >> kPredSeqShift) == (q - 1) ? (v & ((1u << kPredSeqShift) - 1u)) : uint32_t(w);
                     }
                     if (r == 0) {
