@@ -50,7 +50,7 @@ typedef struct wp_vp8_frame {
     int32_t filter_type;        /* 0: filterHeader.level == 0, 1: simple, 2: normal (Vp8Decoder.hx:365-371) */
     int32_t has_alpha;          /* alpha_off is valid */
     uint32_t mb_base;           /* index of this frame's first record in the MB / filter record arrays */
-    uint32_t reserved;
+    uint32_t stile_base;        /* index of this frame's first shifted tile in the workspace; set by wp_vp8_plan */
     uint64_t coeff_base;        /* index (in 32-byte blocks) of this frame's first coefficient block */
     uint64_t y_off, u_off, v_off;   /* byte offsets of the frame's planes inside the Y/U/V slabs */
     uint64_t argb_off;          /* byte offset inside the ARGB slab; tight stride 4*width */
@@ -118,30 +118,52 @@ int wp_device_count(void);
 /* Device-resident batch entry points                                                           */
 /* ------------------------------------------------------------------------------------------ */
 
+/* The lossy kernels exchange pixels through a macroblock-tiled device workspace (384 contiguous bytes
+ * per macroblock, so that the wavefront-scheduled kernels only ever touch whole cache lines):
+ *   R tiles  one per MB record slot (indexed by mb_base): reconstruction output, loop-filter input;
+ *   S tiles  (mbw+1) x (mbh+1) per frame (indexed by stile_base): loop-filter output, shifted by 8 luma
+ *            / 4 chroma pixels so that every byte is final when it is written.
+ * wp_vp8_plan fills stile_base in the (host) descriptors and returns the workspace size for the batch;
+ * call it before copying the descriptors to the device.  The workspace must be 256-byte aligned. */
+int wp_vp8_plan(int n, wp_vp8_frame* frames, uint64_t* work_bytes);
+
 /* Intra prediction + inverse WHT/DCT for n frames.
  * Replaces prepareYBR / inverseWHT16 / inverseDCT4* / reconstructMacroblock / copy
  * (vp8/Vp8Decoder.hx:541-577, 716-770, 810-836, 905-996) and vp8/PredFunc.hx.
- * frames_host: host copy of the descriptors (used for launch geometry); d_frames: same array on
- * the device.  d_mb: WP_MB_WORDS uint32 per MB; d_coeff: int16 blocks. Output: unfiltered planes. */
+ * frames_host: host copy of the descriptors (used for launch geometry and bounds checks); d_frames: same
+ * array on the device.  d_mb: WP_MB_WORDS uint32 per MB; d_coeff: int16 blocks.  Output: R tiles in the
+ * workspace; if d_y/d_u/d_v are non-NULL the unfiltered planes are also written row-major. */
 int wp_vp8_recon_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
-                     const uint32_t* d_mb, const int16_t* d_coeff,
+                     const uint32_t* d_mb, const int16_t* d_coeff, void* d_work, size_t work_bytes,
                      uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, void* stream);
 
-/* In-place loop filter for n frames.  Replaces simpleFilter / normalFilter (vp8/Vp8Decoder.hx:417-486)
- * and vp8/Filter.hx.  d_filt: one filter record per MB (same indexing as d_mb). */
+/* Loop filter for n frames.  Replaces simpleFilter / normalFilter (vp8/Vp8Decoder.hx:417-486) and
+ * vp8/Filter.hx.  d_filt: one filter record per MB (same indexing as d_mb).
+ * d_y/d_u/d_v NULL: filters the R tiles left in the workspace by wp_vp8_recon_dev into S tiles.
+ * d_y/d_u/d_v given: filters those row-major planes in place (tile -> filter -> untile). */
 int wp_vp8_loopfilter_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
-                          const uint32_t* d_filt, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, void* stream);
+                          const uint32_t* d_filt, void* d_work, size_t work_bytes,
+                          uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, void* stream);
 
-/* YUV420 (MB-padded) -> tightly packed A,R,G,B.  Replaces Tools.toArgb (Tools.hx:6-48).
+/* Finishing pass: workspace tiles -> row-major MB-padded planes (ImageData.Yuv420, Vp8Decoder.ensureImg
+ * geometry; optional) and tightly packed A,R,G,B (Tools.toArgb, Tools.hx:6-48; optional).  Frames with
+ * filter_type == 0 are taken from the R tiles, all others from the S tiles. */
+int wp_vp8_finish_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
+                      const void* d_work, size_t work_bytes, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
+                      const uint8_t* d_alpha, uint8_t* d_argb, void* stream);
+
+/* YUV420 (row-major, MB-padded) -> tightly packed A,R,G,B.  Replaces Tools.toArgb (Tools.hx:6-48).
  * d_alpha may be NULL (all frames opaque); frames with has_alpha == 0 get A = 0xFF. */
 int wp_yuv420_to_argb_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
                           const uint8_t* d_y, const uint8_t* d_u, const uint8_t* d_v,
                           const uint8_t* d_alpha, uint8_t* d_argb, void* stream);
 
-/* recon -> loop filter -> convert without leaving the device; the planes keep the filtered YUV
- * (what ImageData.Yuv420 carries).  Replaces Vp8Decoder.decodeFrame's pixel half + Tools.toArgb. */
+/* recon -> loop filter -> finishing pass without leaving the device.  Replaces Vp8Decoder.decodeFrame's
+ * pixel half + Tools.toArgb.  d_y/d_u/d_v (the filtered planes, what ImageData.Yuv420 carries) and
+ * d_argb are each optional. */
 int wp_vp8_decode_to_argb_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
                               const uint32_t* d_mb, const uint32_t* d_filt, const int16_t* d_coeff,
+                              void* d_work, size_t work_bytes,
                               uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
                               const uint8_t* d_alpha, uint8_t* d_argb, void* stream);
 
@@ -163,7 +185,8 @@ int wp_alpha_unfilter_dev(int n, const wp_alpha_frame* frames_host, const wp_alp
 /* ------------------------------------------------------------------------------------------ */
 /* Same semantics as the _dev variants; all pointers are host memory.  Slab sizes are taken from
  * the descriptors (max offset + extent). out_y/out_u/out_v receive the filtered planes and may be
- * NULL when only ARGB is wanted; out_argb may be NULL when only YUV is wanted. */
+ * NULL when only ARGB is wanted; out_argb may be NULL when only YUV is wanted.  The workspace is
+ * planned and allocated internally (stile_base in the caller's descriptors is ignored). */
 int wp_vp8_decode_to_argb(int n, const wp_vp8_frame* frames,
                           const uint32_t* mb, size_t n_mb, const uint32_t* filt,
                           const int16_t* coeff, size_t n_coeff_blocks,

@@ -72,3 +72,60 @@ def test_decode_to_argb_matches_golden(dev_batch):
             # a.webp has no golden; alpha is handled in test_gpu_alpha.py, here the frame is converted opaque
             rgb_exp = ora[i]["to_argb"].reshape(-1, 4)[:, 1:]
             assert np.array_equal(got.reshape(-1, 4)[:, 1:], rgb_exp)
+
+
+def test_decode_to_argb_also_returns_filtered_planes(dev_batch):
+    import torch
+    names, files, ora, db = dev_batch
+    db.y.zero_(); db.u.zero_(); db.v.zero_()
+    db.decode_to_argb(planes=True)
+    torch.cuda.synchronize()
+    for i, n in enumerate(names):
+        y, u, v = db.planes(i)
+        _cmp(n, "Y", y, ora[i]["y"], ora[i]["ystride"])
+        _cmp(n, "U", u, ora[i]["u"], ora[i]["uvstride"])
+        _cmp(n, "V", v, ora[i]["v"], ora[i]["uvstride"])
+
+
+def test_staged_workspace_path_equals_fused(dev_batch):
+    """recon -> loop filter -> finishing pass on the tiled workspace only (what bench.py times per stage)."""
+    import torch
+    names, files, ora, db = dev_batch
+    db.decode_to_argb(planes=False)
+    torch.cuda.synchronize()
+    ref = db.argb.clone()
+    db.argb.zero_()
+    db.recon(planes=False)
+    db.loopfilter(planes=False)
+    db.finish(planes=False, argb=True)
+    torch.cuda.synchronize()
+    assert torch.equal(db.argb, ref)
+    # the row-major conversion entry point (Tools.toArgb on given planes) agrees with the finishing pass
+    db.decode_to_argb(planes=True)
+    db.argb.zero_()
+    db.convert()
+    torch.cuda.synchronize()
+    for i, n in enumerate(names):
+        d = db.b.desc[i]
+        assert torch.equal(db.argb[d.argb_off:d.argb_off + 4 * d.width * d.height], ref[d.argb_off:d.argb_off + 4 * d.width * d.height]), n
+
+
+def test_workspace_checks():
+    """A workspace that is too small, or descriptors that were not planned, are refused before any launch."""
+    import ctypes
+    import torch
+    from webp_amd import parse
+    from webp_amd._lib import WebPError, check, lib
+    from webp_amd.decoder import LossyBatch
+    from webp_amd.device import DeviceLossyBatch
+    db = DeviceLossyBatch(LossyBatch([parse(golden_input("1")).frames[0]] * 2))
+    with pytest.raises(WebPError, match="workspace too small"):
+        check(lib().wp_vp8_recon_dev(db.b.n, db.b.desc, db.frames.data_ptr(), db.mb.data_ptr(), db.coeff.data_ptr(),
+                                     db.work.data_ptr(), db.work_bytes - 1, None, None, None, None))
+    saved = db.b.desc[1].stile_base
+    db.b.desc[1].stile_base = 0
+    with pytest.raises(WebPError, match="wp_vp8_plan"):
+        db.recon(planes=False)
+    db.b.desc[1].stile_base = saved
+    db.decode_to_argb()
+    torch.cuda.synchronize()

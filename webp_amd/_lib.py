@@ -13,7 +13,7 @@ c_u8p = ctypes.POINTER(ctypes.c_uint8)
 class Vp8Frame(ctypes.Structure):          # wp_vp8_frame
     _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("mbw", ctypes.c_int32), ("mbh", ctypes.c_int32),
                 ("filter_type", ctypes.c_int32), ("has_alpha", ctypes.c_int32), ("mb_base", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32), ("coeff_base", ctypes.c_uint64), ("y_off", ctypes.c_uint64),
+                ("stile_base", ctypes.c_uint32), ("coeff_base", ctypes.c_uint64), ("y_off", ctypes.c_uint64),
                 ("u_off", ctypes.c_uint64), ("v_off", ctypes.c_uint64), ("argb_off", ctypes.c_uint64),
                 ("alpha_off", ctypes.c_uint64)]
 
@@ -63,10 +63,12 @@ def lib():
     vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     L.wp_init.argtypes = [i32]
     L.wp_last_error.argtypes = [ctypes.c_char_p, i32]
-    L.wp_vp8_recon_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp]
-    L.wp_vp8_loopfilter_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
+    L.wp_vp8_plan.argtypes = [i32, vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.wp_vp8_recon_dev.argtypes = [i32, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]
+    L.wp_vp8_loopfilter_dev.argtypes = [i32, vp, vp, vp, vp, sz, vp, vp, vp, vp]
+    L.wp_vp8_finish_dev.argtypes = [i32, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp]
     L.wp_yuv420_to_argb_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp]
-    L.wp_vp8_decode_to_argb_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.wp_vp8_decode_to_argb_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp]
     L.wp_vp8l_inverse_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, vp]
     L.wp_alpha_unfilter_dev.argtypes = [i32, vp, vp, vp, vp, vp]
     L.wp_vp8_decode_to_argb.argtypes = [i32, vp, vp, sz, vp, vp, sz, vp, vp, vp, vp, vp]

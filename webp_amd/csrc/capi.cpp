@@ -12,9 +12,14 @@
 // kernel launchers (kernels/*.hip)
 extern "C" {
 int wpk_launch_vp8_recon(int n, int grid, const wp_vp8_frame* d_frames, const void* d_mb, const int16_t* d_coeff,
-                         uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, hipStream_t stream);
+                         uint8_t* d_rtiles, hipStream_t stream);
 int wpk_launch_vp8_filter(int n, int grid, const wp_vp8_frame* d_frames, const uint32_t* d_filt,
-                          uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, hipStream_t stream);
+                          const uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream);
+int wpk_launch_vp8_finish(int n, int chunks, int tile_rows, const wp_vp8_frame* d_frames, const uint8_t* d_rtiles,
+                          const uint8_t* d_stiles, int force_unshifted, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
+                          const uint8_t* d_alpha, uint8_t* d_argb, hipStream_t stream);
+int wpk_launch_vp8_tile(int n, int grid_x, const wp_vp8_frame* d_frames, const uint8_t* d_y, const uint8_t* d_u,
+                        const uint8_t* d_v, uint8_t* d_rtiles, hipStream_t stream);
 int wpk_launch_yuv420_to_argb(int n, int grid_x, const wp_vp8_frame* d_frames, const uint8_t* d_y, const uint8_t* d_u,
                               const uint8_t* d_v, const uint8_t* d_alpha, uint8_t* d_argb, hipStream_t stream);
 int wpk_launch_vp8l(int n, const wp_vp8l_frame* frames_host, const wp_vp8l_frame* d_frames, uint8_t* d_pix, const uint8_t* d_aux,
@@ -47,6 +52,60 @@ int check_vp8_frames(int n, const wp_vp8_frame* f) {
             return fail(WP_ERR_INVALID, "bad wp_vp8_frame at index " + std::to_string(i));
         if ((a.y_off & 15) || (a.u_off & 7) || (a.v_off & 7) || (a.argb_off & 3))
             return fail(WP_ERR_INVALID, "misaligned plane offset in wp_vp8_frame " + std::to_string(i));
+    }
+    return WP_OK;
+}
+
+constexpr size_t kTileBytes = 384;      // one macroblock tile of the workspace (kernels/wp_device.h)
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Workspace layout: [R tiles: one per MB record slot][S tiles: (mbw+1) x (mbh+1) per frame, in frame order]
+struct Vp8Work { size_t n_mb = 0, n_st = 0, r_bytes = 0, total = 0; };
+Vp8Work vp8_work(int n, const wp_vp8_frame* f) {
+    Vp8Work w;
+    for (int i = 0; i < n; ++i) {
+        w.n_mb = std::max(w.n_mb, size_t(f[i].mb_base) + size_t(f[i].mbw) * f[i].mbh);
+        w.n_st += size_t(f[i].mbw + 1) * size_t(f[i].mbh + 1);
+    }
+    w.r_bytes = align_up(w.n_mb * kTileBytes, 256);
+    w.total = w.r_bytes + w.n_st * kTileBytes;
+    return w;
+}
+
+// The kernels index the workspace with mb_base / stile_base from the descriptors: check them against the size the
+// caller really allocated before anything is launched.
+int check_vp8_work(int n, const wp_vp8_frame* f, const void* d_work, size_t work_bytes, Vp8Work& w) {
+    w = vp8_work(n, f);
+    if (!d_work) return fail(WP_ERR_INVALID, "null workspace pointer");
+    if (reinterpret_cast<uintptr_t>(d_work) & 255) return fail(WP_ERR_INVALID, "workspace must be 256-byte aligned");
+    if (w.total > work_bytes) return fail(WP_ERR_INVALID, "workspace too small (see wp_vp8_plan)");
+    size_t st = 0;
+    for (int i = 0; i < n; ++i) {
+        if (size_t(f[i].stile_base) != st) return fail(WP_ERR_INVALID, "stile_base of frame " + std::to_string(i) + " was not set by wp_vp8_plan");
+        st += size_t(f[i].mbw + 1) * size_t(f[i].mbh + 1);
+    }
+    return WP_OK;
+}
+
+struct FinishGeom { int chunks = 1, rows = 1; };
+FinishGeom finish_geom(int n, const wp_vp8_frame* f) {
+    FinishGeom g;
+    for (int i = 0; i < n; ++i) {
+        g.chunks = std::max(g.chunks, (f[i].mbw + 1 + 15) / 16);
+        g.rows = std::max(g.rows, f[i].mbh + 1);
+    }
+    return g;
+}
+
+int launch_finish(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint8_t* d_work, const Vp8Work& w, int force_unshifted,
+                  uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, const uint8_t* d_alpha, uint8_t* d_argb, hipStream_t stream) {
+    // the z dimension of the grid is the frame index (<= 65535 per launch)
+    for (int first = 0; first < n; first += 65535) {
+        const int cnt = std::min(65535, n - first);
+        const FinishGeom g = finish_geom(cnt, fh + first);
+        const int e = wpk_launch_vp8_finish(cnt, g.chunks, g.rows, fd + first, d_work, d_work + w.r_bytes, force_unshifted,
+                                            d_y, d_u, d_v, d_alpha, d_argb, stream);
+        if (e) return hip_fail(hipError_t(e), "vp8_finish launch");
     }
     return WP_OK;
 }
@@ -88,31 +147,79 @@ int wp_last_error(char* buf, int cap) {
     return int(g_error.size());
 }
 
+int wp_vp8_plan(int n, wp_vp8_frame* frames, uint64_t* work_bytes) {
+    int rc = check_vp8_frames(n, frames); if (rc) return rc;
+    size_t st = 0;
+    for (int i = 0; i < n; ++i) {
+        if (st > 0xffffffffull) return fail(WP_ERR_INVALID, "batch too large for 32-bit tile indices");
+        frames[i].stile_base = uint32_t(st);
+        st += size_t(frames[i].mbw + 1) * size_t(frames[i].mbh + 1);
+    }
+    if (work_bytes) *work_bytes = uint64_t(vp8_work(n, frames).total);
+    return WP_OK;
+}
+
 int wp_vp8_recon_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint32_t* d_mb, const int16_t* d_coeff,
-                     uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, void* stream) {
+                     void* d_work, size_t work_bytes, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, void* stream) {
     int rc = ensure_init(); if (rc) return rc;
     rc = check_vp8_frames(n, fh); if (rc) return rc;
     if (n == 0) return WP_OK;
-    if (!fd || !d_mb || !d_y || !d_u || !d_v) return fail(WP_ERR_INVALID, "null device pointer");
+    if (!fd || !d_mb) return fail(WP_ERR_INVALID, "null device pointer");
+    const bool planes = d_y || d_u || d_v;
+    if (planes && !(d_y && d_u && d_v)) return fail(WP_ERR_INVALID, "give all three planes or none");
+    Vp8Work w;
+    rc = check_vp8_work(n, fh, d_work, work_bytes, w); if (rc) return rc;
+    uint8_t* work = static_cast<uint8_t*>(d_work);
     const int grid = std::min(n, g_wavefront_grid);
-    const int e = wpk_launch_vp8_recon(n, grid, fd, d_mb, d_coeff, d_y, d_u, d_v, hipStream_t(stream));
+    const int e = wpk_launch_vp8_recon(n, grid, fd, d_mb, d_coeff, work, hipStream_t(stream));
     if (e) return hip_fail(hipError_t(e), "vp8_recon launch");
+    if (planes) return launch_finish(n, fh, fd, work, w, 1, d_y, d_u, d_v, nullptr, nullptr, hipStream_t(stream));
     return WP_OK;
 }
 
 int wp_vp8_loopfilter_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint32_t* d_filt,
-                          uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, void* stream) {
+                          void* d_work, size_t work_bytes, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, void* stream) {
     int rc = ensure_init(); if (rc) return rc;
     rc = check_vp8_frames(n, fh); if (rc) return rc;
     if (n == 0) return WP_OK;
-    if (!fd || !d_filt || !d_y || !d_u || !d_v) return fail(WP_ERR_INVALID, "null device pointer");
+    if (!fd || !d_filt) return fail(WP_ERR_INVALID, "null device pointer");
+    const bool planes = d_y || d_u || d_v;
+    if (planes && !(d_y && d_u && d_v)) return fail(WP_ERR_INVALID, "give all three planes or none");
+    Vp8Work w;
+    rc = check_vp8_work(n, fh, d_work, work_bytes, w); if (rc) return rc;
+    uint8_t* work = static_cast<uint8_t*>(d_work);
     bool any = false;
     for (int i = 0; i < n; ++i) any = any || fh[i].filter_type != 0;
     if (!any) return WP_OK;
+    if (planes) {
+        for (int first = 0; first < n; first += 65535) {
+            const int cnt = std::min(65535, n - first);
+            const int e = wpk_launch_vp8_tile(cnt, 64, fd + first, d_y, d_u, d_v, work, hipStream_t(stream));
+            if (e) return hip_fail(hipError_t(e), "vp8_tile launch");
+        }
+    }
     const int grid = std::min(n, g_wavefront_grid);
-    const int e = wpk_launch_vp8_filter(n, grid, fd, d_filt, d_y, d_u, d_v, hipStream_t(stream));
+    const int e = wpk_launch_vp8_filter(n, grid, fd, d_filt, work, work + w.r_bytes, hipStream_t(stream));
     if (e) return hip_fail(hipError_t(e), "vp8_filter launch");
+    if (planes) return launch_finish(n, fh, fd, work, w, 0, d_y, d_u, d_v, nullptr, nullptr, hipStream_t(stream));
     return WP_OK;
+}
+
+int wp_vp8_finish_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const void* d_work, size_t work_bytes,
+                      uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, const uint8_t* d_alpha, uint8_t* d_argb, void* stream) {
+    int rc = ensure_init(); if (rc) return rc;
+    rc = check_vp8_frames(n, fh); if (rc) return rc;
+    if (n == 0) return WP_OK;
+    if (!fd) return fail(WP_ERR_INVALID, "null device pointer");
+    const bool planes = d_y || d_u || d_v;
+    if (planes && !(d_y && d_u && d_v)) return fail(WP_ERR_INVALID, "give all three planes or none");
+    if (!planes && !d_argb) return WP_OK;
+    if (d_argb)
+        for (int i = 0; i < n; ++i)
+            if (fh[i].has_alpha && !d_alpha) return fail(WP_ERR_INVALID, "frame has alpha but no alpha slab was given");
+    Vp8Work w;
+    rc = check_vp8_work(n, fh, d_work, work_bytes, w); if (rc) return rc;
+    return launch_finish(n, fh, fd, static_cast<const uint8_t*>(d_work), w, 0, d_y, d_u, d_v, d_alpha, d_argb, hipStream_t(stream));
 }
 
 int wp_yuv420_to_argb_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint8_t* d_y, const uint8_t* d_u,
@@ -139,14 +246,13 @@ int wp_yuv420_to_argb_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd,
 }
 
 int wp_vp8_decode_to_argb_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint32_t* d_mb, const uint32_t* d_filt,
-                              const int16_t* d_coeff, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, const uint8_t* d_alpha,
-                              uint8_t* d_argb, void* stream) {
-    int rc = wp_vp8_recon_dev(n, fh, fd, d_mb, d_coeff, d_y, d_u, d_v, stream);
+                              const int16_t* d_coeff, void* d_work, size_t work_bytes, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
+                              const uint8_t* d_alpha, uint8_t* d_argb, void* stream) {
+    int rc = wp_vp8_recon_dev(n, fh, fd, d_mb, d_coeff, d_work, work_bytes, nullptr, nullptr, nullptr, stream);
     if (rc) return rc;
-    rc = wp_vp8_loopfilter_dev(n, fh, fd, d_filt, d_y, d_u, d_v, stream);
+    rc = wp_vp8_loopfilter_dev(n, fh, fd, d_filt, d_work, work_bytes, nullptr, nullptr, nullptr, stream);
     if (rc) return rc;
-    if (d_argb) rc = wp_yuv420_to_argb_dev(n, fh, fd, d_y, d_u, d_v, d_alpha, d_argb, stream);
-    return rc;
+    return wp_vp8_finish_dev(n, fh, fd, d_work, work_bytes, d_y, d_u, d_v, d_alpha, d_argb, stream);
 }
 
 int wp_vp8l_inverse_dev(int n, const wp_vp8l_frame* fh, const wp_vp8l_frame* fd, uint8_t* d_pix, const uint8_t* d_aux,
@@ -206,8 +312,6 @@ struct DevBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
-size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
 struct Vp8Extents { size_t y = 0, u = 0, v = 0, argb = 0, alpha = 0; };
 Vp8Extents vp8_extents(int n, const wp_vp8_frame* f) {
     Vp8Extents e;
@@ -238,16 +342,24 @@ int wp_vp8_decode_to_argb(int n, const wp_vp8_frame* frames, const uint32_t* mb,
         if (frames[i].coeff_base > n_coeff_blocks) return fail(WP_ERR_INVALID, "coeff_base out of range");
     }
     const Vp8Extents ex = vp8_extents(n, frames);
-    DevBuf dfr, dmb, dfl, dco, dy, du, dv, da, dargb;
+    std::vector<wp_vp8_frame> planned(frames, frames + n);      // the caller's descriptors stay untouched
+    uint64_t work_bytes = 0;
+    if ((rc = wp_vp8_plan(n, planned.data(), &work_bytes))) return rc;
+    frames = planned.data();
+    const bool want_planes = out_y || out_u || out_v;
+    DevBuf dfr, dmb, dfl, dco, dy, du, dv, da, dargb, dwork;
     if ((rc = dfr.upload(frames, sizeof(wp_vp8_frame) * size_t(n)))) return rc;
+    if ((rc = dwork.alloc(size_t(work_bytes)))) return rc;
     if ((rc = dmb.upload(mb, n_mb * 16))) return rc;
     if ((rc = dfl.upload(filt, n_mb * 4))) return rc;
     if ((rc = dco.upload(coeff, n_coeff_blocks * 32))) return rc;
-    if ((rc = dy.alloc(ex.y)) || (rc = du.alloc(ex.u)) || (rc = dv.alloc(ex.v))) return rc;
+    if (want_planes && ((rc = dy.alloc(ex.y)) || (rc = du.alloc(ex.u)) || (rc = dv.alloc(ex.v)))) return rc;
     if (ex.alpha) { if (!alpha) return fail(WP_ERR_INVALID, "alpha slab missing"); if ((rc = da.upload(alpha, ex.alpha))) return rc; }
     if (out_argb && (rc = dargb.alloc(ex.argb))) return rc;
     rc = wp_vp8_decode_to_argb_dev(n, frames, dfr.as<wp_vp8_frame>(), dmb.as<uint32_t>(), dfl.as<uint32_t>(), dco.as<int16_t>(),
-                                   dy.as<uint8_t>(), du.as<uint8_t>(), dv.as<uint8_t>(), ex.alpha ? da.as<uint8_t>() : nullptr,
+                                   dwork.p, size_t(work_bytes),
+                                   want_planes ? dy.as<uint8_t>() : nullptr, want_planes ? du.as<uint8_t>() : nullptr,
+                                   want_planes ? dv.as<uint8_t>() : nullptr, ex.alpha ? da.as<uint8_t>() : nullptr,
                                    out_argb ? dargb.as<uint8_t>() : nullptr, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());

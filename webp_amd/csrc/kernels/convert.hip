@@ -7,22 +7,9 @@
 // checks all 2^24 of them.  Pure streaming: each thread converts 4 horizontally adjacent pixels
 // (one dword of luma, two chroma samples) and stores 16 bytes.
 #include "wp_device.h"
+#include "wp_convert.h"
 
 namespace wpk {
-
-__device__ __forceinline__ uint32_t round255(double x) {
-    x = fmax(0.0, fmin(255.0, x));
-    return uint32_t(int(floor(__dadd_rn(x, 0.5))));
-}
-
-// one pixel -> bytes A,R,G,B in memory order (little-endian dword: A | R<<8 | G<<16 | B<<24)
-__device__ __forceinline__ uint32_t convert_px(int yv, int cb, int cr, uint32_t a) {
-    const double Yd = double(yv), Cb = double(cb - 128), Cr = double(cr - 128);
-    const double R = __dadd_rn(Yd, __dmul_rn(1.402, Cr));
-    const double G = __dsub_rn(__dsub_rn(Yd, __dmul_rn(0.344136, Cb)), __dmul_rn(0.714136, Cr));
-    const double B = __dadd_rn(Yd, __dmul_rn(1.772, Cb));
-    return a | round255(R) << 8 | round255(G) << 16 | round255(B) << 24;
-}
 
 __global__ __launch_bounds__(256)
 void yuv420_to_argb_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* __restrict__ Yp, const uint8_t* __restrict__ Up,

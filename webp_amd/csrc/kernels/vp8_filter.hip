@@ -1,4 +1,5 @@
-// VP8 loop filter (simple and normal), in place on the reconstructed planes, for a batch of frames.
+// VP8 loop filter (simple and normal) for a batch of frames: reads the reconstructed macroblock tiles (R),
+// writes the filtered image as shifted tiles (S) -- see wp_device.h for the two layouts.
 //
 // Replaces simpleFilter / normalFilter (vp8/Vp8Decoder.hx:417-486) and vp8/Filter.hx.
 //
@@ -7,26 +8,33 @@
 // upper neighbours.  MB (x,y) therefore has to run after (x-1,y), (x,y-1) and (x+1,y-1) -- the same
 // 2:1 anti-diagonal skew as reconstruction -- and any schedule that respects it is bit-identical to
 // raster order.  As in vp8_recon.hip one wavefront owns a band of 4 MB rows (16 lanes per row,
-// lockstep skew).  A group keeps a 20x20 luma tile (+ two 12x12 chroma tiles) in LDS: vertical
-// edges are filtered with lane = pixel row, horizontal edges with lane = pixel column.  The four
-// right-most columns stay in the tile for the next MB; the four bottom rows go through a small LDS
-// ring to the group below; band-to-band hand-over goes through the planes themselves
-// (workgroup-scope release/acquire, same CU).
+// lockstep skew).  A group keeps a 24-row luma tile with two 16-column MB slots (+ two 12-row chroma
+// tiles with two 8-column slots) in LDS: vertical edges are filtered with lane = pixel row, horizontal
+// edges with lane = pixel column.  After MB (x,y) everything up to row 16y+12 / column 16x+12 is final,
+// so the group emits S tile (x,y) = rows 16y-8..16y+7, cols 16x-8..16x+7 (chroma: 8y-4.., 8x-4..): every
+// output byte is written exactly once, 384 contiguous bytes per MB.  The eight bottom rows (state after
+// this MB row's filtering) go to the group below through an LDS ring; the last row of a band writes
+// them as the top half of the S tiles of the next tile row, from where the next band (or, for the
+// frame's last row, the finishing pass) picks them up (workgroup-scope release/acquire, same CU).
 #include "wp_device.h"
 
 namespace wpk {
 
-struct FilterTile {
-    uint8_t y[20][24];          // rows 0..3: above, 4..19: MB; cols 0..3: left, 4..19: MB
-    uint8_t c[2][12][12];       // same shape at chroma scale (4 + 8)
-    uint8_t pad[32];            // 800 B = 200 dwords: the four groups' tiles start 8 banks apart
+struct alignas(16) FilterTile {
+    uint8_t y[24][32];          // rows 0..7: the 8 rows above, 8..23: MB rows; cols: MB slot (x & 1) * 16
+    uint8_t c[2][12][16];       // rows 0..3: above, 4..11: MB rows; cols: slot (x & 1) * 8
+    uint8_t pad[32];            // 1184 B = 296 dwords: the four groups' tiles start 8 banks apart
 };
-struct FilterWaveLds {
+struct alignas(16) FilterWaveLds {
     FilterTile tile[kBandRows];
-    uint8_t ring_y[kBandRows][4][64];      // ring_y[g][row][abs_col & 63]: 4 bottom luma rows of the MB row above group g
-    uint8_t ring_c[kBandRows][2][4][32];   // same for Cb / Cr
+    alignas(16) uint8_t ring_y[kBandRows][8][64];      // ring_y[g][row][abs_col & 63]: 8 bottom luma rows of the MB row above group g
+    uint8_t ring_c[kBandRows][2][4][32];   // same for Cb / Cr (4 rows)
 };
 
+__device__ __forceinline__ uint2& t64(uint8_t* p) { return *reinterpret_cast<uint2*>(p); }
+__device__ __forceinline__ uint4& t128(uint8_t* p) { return *reinterpret_cast<uint4*>(p); }
+__device__ __forceinline__ void unpack4(uint32_t w, int* v) { v[0] = w & 0xff; v[1] = (w >> 8) & 0xff; v[2] = (w >> 16) & 0xff; v[3] = w >> 24; }
+__device__ __forceinline__ uint32_t pack4i(const int* v) { return uint32_t(v[0]) | uint32_t(v[1]) << 8 | uint32_t(v[2]) << 16 | uint32_t(v[3]) << 24; }
 __device__ __forceinline__ uint32_t& t32(uint8_t* p) { return *reinterpret_cast<uint32_t*>(p); }
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int clamp127(int v) { return clampi(v, -127, 127); }   // Filter.hx:16-18 (symmetric)
@@ -112,7 +120,7 @@ __device__ __forceinline__ void filter_line(int (&v)[N], bool simple, bool mb_ed
 
 __global__ __launch_bounds__(kWavesPerWG * kWave)
 void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, const uint32_t* __restrict__ filt,
-                       uint8_t* Yp, uint8_t* Up, uint8_t* Vp) {
+                       const uint8_t* __restrict__ Rp, uint8_t* Sp) {
     __shared__ FilterWaveLds lds_all[kWavesPerWG];
     __shared__ uint32_t progress[kWavesPerWG];
 
@@ -122,6 +130,10 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
     const int l = lane & 15;
     FilterWaveLds& lds = lds_all[wave];
     FilterTile& T = lds.tile[g];
+    // lane roles in the row-wise phases
+    const int lp = l >> 3, lr = l & 7;                    // chroma plane / chroma row
+    const int hr = l >> 1, hh = l & 1;                    // hand-over: luma row 0..7, 8-byte half
+    const int hcr = (l >> 1) & 3;                         // hand-over: chroma row 0..3 (plane = lp, 4-byte half = hh)
 
     if (threadIdx.x < kWavesPerWG) progress[threadIdx.x] = 0;
     __syncthreads();
@@ -133,10 +145,9 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
         const int n_bands = (mbh + kBandRows - 1) / kBandRows;
         if (fr.filter_type == 0) { seq += uint32_t(n_bands); continue; }      // filterHeader.level == 0 (Vp8Decoder.hx:365)
         const bool simple = fr.filter_type == 1;
-        const int ystride = 16 * mbw, cstride = 8 * mbw;
-        uint8_t* const Y = Yp + fr.y_off;
-        uint8_t* const U = Up + fr.u_off;
-        uint8_t* const V = Vp + fr.v_off;
+        const uint8_t* const R = Rp + size_t(fr.mb_base) * kTileBytes;
+        uint8_t* const S = Sp + size_t(fr.stile_base) * kTileBytes;
+        const int spitch = mbw + 1;
 
         for (int band = 0; band < n_bands; ++band) {
             const uint32_t q = seq + uint32_t(band);
@@ -148,28 +159,28 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
             const int prev_wave = (wave + kWavesPerWG - 1) % kWavesPerWG;
             const int rows_here = min(kBandRows, mbh - band * kBandRows);
             const int n_steps = mbw + 2 * (rows_here - 1);
+            const bool last_row = g == rows_here - 1;             // its bottom rows leave the band through the S tiles
 
             // Everything a step reads from global memory is fetched one step ahead (registers), so no global
-            // round trip sits on a step's critical path: the MB's own pixels and filter record, and -- for the
-            // band's first row -- the four rows above (which makes this band trail the one above by 3 MBs).
-            const int lp = l >> 3, lr = l & 7;                    // chroma: plane / row handled by this lane in the row-wise phases
-            const uint8_t* yrow = Y + size_t(16 * (row_ok ? y : 0) + l) * ystride;
-            const uint8_t* crow = (lp ? V : U) + size_t(8 * (row_ok ? y : 0) + lr) * cstride;
-            const uint32_t* frow = filt + size_t(fr.mb_base) + size_t(row_ok ? y : 0) * mbw;
-            const bool top_lane_y = has_above && g == 0 && l < 4;
-            const bool top_lane_c = has_above && g == 0 && !simple && l >= 4 && l < 12;
-            const uint8_t* trow_y = Y + size_t(16 * (row_ok ? y : 0) - (y > 0 ? 4 : 0) + (l & 3)) * ystride;
-            const uint8_t* trow_c = (((l - 4) >> 2) & 1 ? V : U) + size_t(8 * (row_ok ? y : 0) - (y > 0 ? 4 : 0) + ((l - 4) & 3)) * cstride;
-            uint4 nx_y = make_uint4(0, 0, 0, 0), nx_ty = make_uint4(0, 0, 0, 0);
-            uint2 nx_c = make_uint2(0, 0), nx_tc = make_uint2(0, 0);
-            uint32_t nx_fp = 0;
+            // round trip sits on a step's critical path: the MB's own tile and filter record, and -- for the
+            // band's first row -- the eight rows above (which makes this band trail the one above by 3 MBs).
+            const int yy = row_ok ? y : 0;
+            const uint8_t* rrow = R + size_t(yy) * mbw * kTileBytes;                 // R tiles of this MB row
+            uint8_t* srow = S + size_t(yy) * spitch * kTileBytes;                    // S tiles of tile row y
+            const uint32_t* frow = filt + size_t(fr.mb_base) + size_t(yy) * mbw;
+            const bool top_lane = has_above && g == 0;
+            // above rows of MB x: S(x, y) bytes 8..15 of rows 0..7 (cols 0..7) and S(x+1, y) bytes 0..7 (cols 8..15)
+            const uint8_t* trow_y = srow + size_t(hh) * kTileBytes + 16 * hr + 8 * (1 - hh);
+            const uint8_t* trow_c = srow + size_t(hh) * kTileBytes + kTileCb + 64 * lp + 8 * hcr + 4 * (1 - hh);
+            uint4 nx_y = make_uint4(0, 0, 0, 0);
+            uint2 nx_c = make_uint2(0, 0), nx_ty = make_uint2(0, 0);
+            uint32_t nx_fp = 0, nx_tc = 0;
             if (has_above) wait_progress(&progress[prev_wave], ((q - 1) << kSeqShift) | uint32_t(min(2, mbw)));
             if (row_ok && g == 0) {
-                nx_y = *reinterpret_cast<const uint4*>(yrow);
-                if (!simple) nx_c = *reinterpret_cast<const uint2*>(crow);
+                nx_y = *reinterpret_cast<const uint4*>(rrow + 16 * l);
+                nx_c = *reinterpret_cast<const uint2*>(rrow + kTileCb + 8 * l);
                 nx_fp = frow[0];
-                if (top_lane_y) nx_ty = *reinterpret_cast<const uint4*>(trow_y);
-                if (top_lane_c) nx_tc = *reinterpret_cast<const uint2*>(trow_c);
+                if (top_lane) { nx_ty = *reinterpret_cast<const uint2*>(trow_y); nx_tc = *reinterpret_cast<const uint32_t*>(trow_c); }
             }
             settle(nx_y); settle(nx_ty); settle(nx_c); settle(nx_tc); settle(nx_fp);
             uint32_t pending_publish = 0;
@@ -177,100 +188,79 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
             for (int s = 0; s < n_steps; ++s) {
                 const int x = s - 2 * g;
                 const bool act = row_ok && x >= 0 && x < mbw;
-                const uint4 cur_y = nx_y, cur_ty = nx_ty;
-                const uint2 cur_c = nx_c, cur_tc = nx_tc;
-                const uint32_t fp = nx_fp;
+                const uint4 cur_y = nx_y;
+                const uint2 cur_c = nx_c, cur_ty = nx_ty;
+                const uint32_t fp = nx_fp, cur_tc = nx_tc;
                 if (has_above && s + 1 < mbw)
                     wait_progress(&progress[prev_wave], ((q - 1) << kSeqShift) | uint32_t(min(s + 3, mbw)));
                 if (row_ok && x + 1 >= 0 && x + 1 < mbw) {
-                    nx_y = *reinterpret_cast<const uint4*>(yrow + 16 * (x + 1));
-                    if (!simple) nx_c = *reinterpret_cast<const uint2*>(crow + 8 * (x + 1));
+                    const size_t o = size_t(x + 1) * kTileBytes;
+                    nx_y = *reinterpret_cast<const uint4*>(rrow + o + 16 * l);
+                    nx_c = *reinterpret_cast<const uint2*>(rrow + o + kTileCb + 8 * l);
                     nx_fp = frow[x + 1];
-                    if (top_lane_y) nx_ty = *reinterpret_cast<const uint4*>(trow_y + 16 * (x + 1));
-                    if (top_lane_c) nx_tc = *reinterpret_cast<const uint2*>(trow_c + 8 * (x + 1));
+                    if (top_lane) { nx_ty = *reinterpret_cast<const uint2*>(trow_y + o); nx_tc = *reinterpret_cast<const uint32_t*>(trow_c + o); }
                 }
 
                 const int level = int(fp & 0xff), ilevel = int((fp >> 8) & 0xff), hlevel = int((fp >> 16) & 0xff);
                 const bool inner = (fp >> 24) & 1;
                 const bool do_filter = act && level != 0;                   // `if (f.level == 0) continue` (:421, :449)
+                const int cb = 16 * (x & 1), pb = 16 - cb;                  // luma column base of this MB's slot / the previous MB's
+                const int cb8 = cb >> 1, pb8 = pb >> 1;
                 if (act) {
-                    // ---- 1. slide the tile: right-most 4 columns become the left strip ----
-                    if (x > 0) {
-                        t32(&T.y[4 + l][0]) = t32(&T.y[4 + l][16]);
-                        if (!simple) t32(&T.c[lp][4 + lr][0]) = t32(&T.c[lp][4 + lr][8]);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    // own macroblock, straight from the reconstructed planes (nobody has touched it yet)
-                    t32(&T.y[4 + l][4]) = cur_y.x; t32(&T.y[4 + l][8]) = cur_y.y; t32(&T.y[4 + l][12]) = cur_y.z; t32(&T.y[4 + l][16]) = cur_y.w;
-                    if (!simple) { t32(&T.c[lp][4 + lr][4]) = cur_c.x; t32(&T.c[lp][4 + lr][8]) = cur_c.y; }
-                    // four rows above: from the group above (LDS ring) or, for the band's first row, from the planes
+                    // ---- 1. own macroblock (nobody has touched it yet) and the rows above it ----
+                    t128(&T.y[8 + l][cb]) = cur_y;
+                    t64(&T.c[lp][4 + lr][cb8]) = cur_c;
                     if (y > 0) {
                         if (g > 0) {
-                            if (l < 4) {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) t32(&T.y[l][4 + 4 * k]) = t32(&lds.ring_y[g][l][(16 * x + 4 * k) & 63]);
-                            } else if (!simple && l < 12) {
-                                const int p = (l - 4) >> 2, r = (l - 4) & 3;
-                                t32(&T.c[p][r][4]) = t32(&lds.ring_c[g][p][r][(8 * x) & 31]);
-                                t32(&T.c[p][r][8]) = t32(&lds.ring_c[g][p][r][(8 * x + 4) & 31]);
-                            }
+                            t64(&T.y[hr][cb + 8 * hh]) = t64(&lds.ring_y[g][hr][(16 * x + 8 * hh) & 63]);
+                            t32(&T.c[lp][hcr][cb8 + 4 * hh]) = t32(&lds.ring_c[g][lp][hcr][(8 * x + 4 * hh) & 31]);
                         } else {
-                            if (l < 4) {
-                                t32(&T.y[l][4]) = cur_ty.x; t32(&T.y[l][8]) = cur_ty.y; t32(&T.y[l][12]) = cur_ty.z; t32(&T.y[l][16]) = cur_ty.w;
-                            } else if (!simple && l < 12) {
-                                const int p = (l - 4) >> 2, r = (l - 4) & 3;
-                                t32(&T.c[p][r][4]) = cur_tc.x; t32(&T.c[p][r][8]) = cur_tc.y;
-                            }
+                            t64(&T.y[hr][cb + 8 * hh]) = cur_ty;
+                            t32(&T.c[lp][hcr][cb8 + 4 * hh]) = cur_tc;
                         }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
 
                 if (do_filter) {
-                    // ---- 2a. vertical edges: lane = pixel row ----
+                    // ---- 2a. vertical edges: lane = pixel row; columns -4..15 relative to the MB ----
                     {
                         int v[20];
-#pragma unroll
-                        for (int k = 0; k < 5; ++k) {
-                            const uint32_t w = t32(&T.y[4 + l][4 * k]);
-                            v[4 * k] = w & 0xff; v[4 * k + 1] = (w >> 8) & 0xff; v[4 * k + 2] = (w >> 16) & 0xff; v[4 * k + 3] = w >> 24;
-                        }
+                        unpack4(t32(&T.y[8 + l][pb + 12]), v);
+                        const uint4 w = t128(&T.y[8 + l][cb]);
+                        unpack4(w.x, v + 4); unpack4(w.y, v + 8); unpack4(w.z, v + 12); unpack4(w.w, v + 16);
                         filter_line<20>(v, simple, x > 0, inner, level, ilevel, hlevel);
-#pragma unroll
-                        for (int k = 0; k < 5; ++k)
-                            t32(&T.y[4 + l][4 * k]) = uint32_t(v[4 * k]) | uint32_t(v[4 * k + 1]) << 8 | uint32_t(v[4 * k + 2]) << 16 | uint32_t(v[4 * k + 3]) << 24;
+                        t32(&T.y[8 + l][pb + 12]) = pack4i(v);
+                        t128(&T.y[8 + l][cb]) = make_uint4(pack4i(v + 4), pack4i(v + 8), pack4i(v + 12), pack4i(v + 16));
                     }
                     if (!simple) {
                         int v[12];
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const uint32_t w = t32(&T.c[lp][4 + lr][4 * k]);
-                            v[4 * k] = w & 0xff; v[4 * k + 1] = (w >> 8) & 0xff; v[4 * k + 2] = (w >> 16) & 0xff; v[4 * k + 3] = w >> 24;
-                        }
+                        unpack4(t32(&T.c[lp][4 + lr][pb8 + 4]), v);
+                        const uint2 w = t64(&T.c[lp][4 + lr][cb8]);
+                        unpack4(w.x, v + 4); unpack4(w.y, v + 8);
                         filter_line<12>(v, false, x > 0, inner, level, ilevel, hlevel);
-#pragma unroll
-                        for (int k = 0; k < 3; ++k)
-                            t32(&T.c[lp][4 + lr][4 * k]) = uint32_t(v[4 * k]) | uint32_t(v[4 * k + 1]) << 8 | uint32_t(v[4 * k + 2]) << 16 | uint32_t(v[4 * k + 3]) << 24;
+                        t32(&T.c[lp][4 + lr][pb8 + 4]) = pack4i(v);
+                        t64(&T.c[lp][4 + lr][cb8]) = make_uint2(pack4i(v + 4), pack4i(v + 8));
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (do_filter) {
-                    // ---- 2b. horizontal edges: lane = pixel column ----
+                    // ---- 2b. horizontal edges: lane = pixel column; rows -4..15 relative to the MB ----
                     {
                         int v[20];
 #pragma unroll
-                        for (int k = 0; k < 20; ++k) v[k] = T.y[k][4 + l];
+                        for (int k = 0; k < 20; ++k) v[k] = T.y[4 + k][cb + l];
                         filter_line<20>(v, simple, y > 0, inner, level, ilevel, hlevel);
 #pragma unroll
-                        for (int k = 1; k < 19; ++k) T.y[k][4 + l] = uint8_t(v[k]);
+                        for (int k = 1; k < 19; ++k) T.y[4 + k][cb + l] = uint8_t(v[k]);
                     }
                     if (!simple) {
                         int v[12];
 #pragma unroll
-                        for (int k = 0; k < 12; ++k) v[k] = T.c[lp][k][4 + lr];
+                        for (int k = 0; k < 12; ++k) v[k] = T.c[lp][k][cb8 + lr];
                         filter_line<12>(v, false, y > 0, inner, level, ilevel, hlevel);
 #pragma unroll
-                        for (int k = 1; k < 11; ++k) T.c[lp][k][4 + lr] = uint8_t(v[k]);
+                        for (int k = 1; k < 11; ++k) T.c[lp][k][cb8 + lr] = uint8_t(v[k]);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -284,37 +274,34 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
                     pending_publish = done >= 1 ? ((q << kSeqShift) | uint32_t(done)) : 0u;
                 }
 
-                if (do_filter) {
-                    // ---- 3. write back everything this macroblock may have modified ----
-                    {
-                        uint8_t* dst = Y + size_t(16 * y + l) * ystride + 16 * x;
-                        if (x > 0) *reinterpret_cast<uint32_t*>(dst - 4) = t32(&T.y[4 + l][0]);
-                        *reinterpret_cast<uint4*>(dst) = make_uint4(t32(&T.y[4 + l][4]), t32(&T.y[4 + l][8]), t32(&T.y[4 + l][12]), t32(&T.y[4 + l][16]));
-                        if (y > 0 && l >= 1 && l < 4) {
-                            uint8_t* up = Y + size_t(16 * y - 4 + l) * ystride + 16 * x;
-                            *reinterpret_cast<uint4*>(up) = make_uint4(t32(&T.y[l][4]), t32(&T.y[l][8]), t32(&T.y[l][12]), t32(&T.y[l][16]));
-                        }
+                if (act) {
+                    // ---- 3. emit S tile (x, y): rows -8..7, cols -8..7 relative to the MB, all final ----
+                    uint8_t* st = srow + size_t(x) * kTileBytes;
+                    const uint2 a = t64(&T.y[l][pb + 8]), b = t64(&T.y[l][cb]);
+                    *reinterpret_cast<uint4*>(st + 16 * l) = make_uint4(a.x, a.y, b.x, b.y);
+                    *reinterpret_cast<uint2*>(st + kTileCb + 8 * l) = make_uint2(t32(&T.c[lp][lr][pb8 + 4]), t32(&T.c[lp][lr][cb8]));
+                    if (x == mbw - 1) {        // right-most tile column: cols 8..15 (left half of tile mbw)
+                        *reinterpret_cast<uint2*>(st + kTileBytes + 16 * l) = t64(&T.y[l][cb + 8]);
+                        *reinterpret_cast<uint32_t*>(st + kTileBytes + kTileCb + 8 * l) = t32(&T.c[lp][lr][cb8 + 4]);
                     }
-                    if (!simple) {
-                        uint8_t* dst = (lp ? V : U) + size_t(8 * y + lr) * cstride + 8 * x;
-                        if (x > 0) *reinterpret_cast<uint32_t*>(dst - 4) = t32(&T.c[lp][4 + lr][0]);
-                        *reinterpret_cast<uint2*>(dst) = make_uint2(t32(&T.c[lp][4 + lr][4]), t32(&T.c[lp][4 + lr][8]));
-                        if (y > 0 && (l & 3) != 0 && l < 8) {
-                            const int pp = l >> 2, rr = l & 3;
-                            uint8_t* up = (pp ? V : U) + size_t(8 * y - 4 + rr) * cstride + 8 * x;
-                            *reinterpret_cast<uint2*>(up) = make_uint2(t32(&T.c[pp][rr][4]), t32(&T.c[pp][rr][8]));
+                    // ---- 4. hand the eight bottom rows (cols -8..7; state after this MB) down ----
+                    const uint2 vy = t64(&T.y[16 + hr][hh ? cb : pb + 8]);
+                    const uint32_t vc = t32(&T.c[lp][8 + hcr][hh ? cb8 : pb8 + 4]);
+                    if (!last_row) {
+                        t64(&lds.ring_y[g + 1][hr][(16 * x - 8 + 8 * hh) & 63]) = vy;
+                        t32(&lds.ring_c[g + 1][lp][hcr][(8 * x - 4 + 4 * hh) & 31]) = vc;
+                        if (x == mbw - 1 && hh) {   // cols 8..15 of the last MB
+                            t64(&lds.ring_y[g + 1][hr][(16 * x + 8) & 63]) = t64(&T.y[16 + hr][cb + 8]);
+                            t32(&lds.ring_c[g + 1][lp][hcr][(8 * x + 4) & 31]) = t32(&T.c[lp][8 + hcr][cb8 + 4]);
                         }
-                    }
-                }
-                // ---- 4. hand the four bottom rows (current state) to the group below ----
-                if (act && g + 1 < kBandRows) {
-                    const int r = l >> 2, k = l & 3;           // 4 rows x 4 dwords of the MB itself
-                    t32(&lds.ring_y[g + 1][r][(16 * x + 4 * k) & 63]) = t32(&T.y[16 + r][4 + 4 * k]);
-                    if (x > 0 && l < 4) t32(&lds.ring_y[g + 1][l][(16 * x - 4) & 63]) = t32(&T.y[16 + l][0]);
-                    if (!simple) {
-                        const int rr = (l >> 1) & 3, kk = l & 1;   // 2 planes x 4 rows x 2 dwords
-                        t32(&lds.ring_c[g + 1][lp][rr][(8 * x + 4 * kk) & 31]) = t32(&T.c[lp][8 + rr][4 + 4 * kk]);
-                        if (x > 0 && l < 8) t32(&lds.ring_c[g + 1][l >> 2][l & 3][(8 * x - 4) & 31]) = t32(&T.c[l >> 2][8 + (l & 3)][0]);
+                    } else {
+                        uint8_t* sn = st + size_t(spitch) * kTileBytes;       // S tile (x, y+1); tile row mbh exists
+                        *reinterpret_cast<uint2*>(sn + 16 * hr + 8 * hh) = vy;
+                        *reinterpret_cast<uint32_t*>(sn + kTileCb + 64 * lp + 8 * hcr + 4 * hh) = vc;
+                        if (x == mbw - 1 && hh) {
+                            *reinterpret_cast<uint2*>(sn + kTileBytes + 16 * hr) = t64(&T.y[16 + hr][cb + 8]);
+                            *reinterpret_cast<uint32_t*>(sn + kTileBytes + kTileCb + 64 * lp + 8 * hcr) = t32(&T.c[lp][8 + hcr][cb8 + 4]);
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -328,8 +315,8 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
 }  // namespace wpk
 
 extern "C" int wpk_launch_vp8_filter(int n, int grid, const wp_vp8_frame* d_frames, const uint32_t* d_filt,
-                                     uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, hipStream_t stream) {
+                                     const uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream) {
     hipLaunchKernelGGL(wpk::vp8_filter_kernel, dim3(grid), dim3(wpk::kWavesPerWG * wpk::kWave), 0, stream,
-                       n, d_frames, d_filt, d_y, d_u, d_v);
+                       n, d_frames, d_filt, d_rtiles, d_stiles);
     return int(hipGetLastError());
 }

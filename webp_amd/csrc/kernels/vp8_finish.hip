@@ -1,0 +1,122 @@
+// Finishing pass of the lossy path: macroblock tiles (wp_device.h) -> row-major Y/U/V planes (what
+// ImageData.Yuv420 carries, Vp8Decoder.ensureImg geometry) and tightly packed A,R,G,B (Tools.toArgb,
+// Tools.hx:6-48), plus the inverse helper that tiles row-major planes for the stand-alone loop filter.
+//
+// Pure streaming.  A workgroup takes up to 16 horizontally adjacent tiles (6 KB, contiguous in memory),
+// parks them in LDS and writes rows: a wavefront emits 1 KB of contiguous ARGB (256 pixels of one row),
+// 256 B of luma or 128 B of chroma per instruction.  Frames whose loop filter is off are read from the
+// R tiles (no shift), all others from the S tiles (shift 8 luma / 4 chroma).
+#include "wp_device.h"
+#include "wp_convert.h"
+
+namespace wpk {
+
+constexpr int kFinishTiles = 16;
+
+__global__ __launch_bounds__(256)
+void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* __restrict__ Rp, const uint8_t* __restrict__ Sp,
+                       int force_unshifted, uint8_t* Yp, uint8_t* Up, uint8_t* Vp, const uint8_t* __restrict__ Ap, uint8_t* out) {
+    __shared__ uint4 tiles4[kFinishTiles * kTileBytes / 16];
+    const wp_vp8_frame& fr = frames[blockIdx.z];
+    const int mbw = fr.mbw, mbh = fr.mbh, width = fr.width, height = fr.height;
+    const bool shifted = fr.filter_type != 0 && !force_unshifted;
+    const int shift = shifted ? kFiltShift : 0;
+    const int ntx = mbw + (shifted ? 1 : 0), nty = mbh + (shifted ? 1 : 0);
+    const int ty = blockIdx.y, tx0 = blockIdx.x * kFinishTiles;
+    if (ty >= nty || tx0 >= ntx) return;
+    const int nt = min(kFinishTiles, ntx - tx0);
+    const uint8_t* src = (shifted ? Sp + size_t(fr.stile_base) * kTileBytes : Rp + size_t(fr.mb_base) * kTileBytes)
+                       + (size_t(ty) * ntx + tx0) * kTileBytes;
+    const int t = threadIdx.x;
+    for (int i = t; i < nt * (kTileBytes / 16); i += 256) tiles4[i] = reinterpret_cast<const uint4*>(src)[i];
+    __syncthreads();
+    const uint32_t* tiles32 = reinterpret_cast<const uint32_t*>(tiles4);
+    const uint16_t* tiles16 = reinterpret_cast<const uint16_t*>(tiles4);
+
+    const int ystride = 16 * mbw, cstride = 8 * mbw;
+    uint8_t* const Y = Yp ? Yp + fr.y_off : nullptr;
+    const uint8_t* A = (Ap != nullptr && fr.has_alpha) ? Ap + fr.alpha_off : nullptr;
+    uint8_t* const dst = out ? out + fr.argb_off : nullptr;
+
+    // ---- luma rows + ARGB: thread = 4 pixels, wavefront = 256 pixels of one row ----
+    const int q = t & 63, k = q >> 2, c4 = (q & 3) * 4;
+    const int px = 16 * (tx0 + k) - shift + c4;
+    if (k < nt && px >= 0 && px < ystride) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 4 + (t >> 6);
+            const int py = 16 * ty - shift + r;
+            if (py < 0 || py >= 16 * mbh) continue;
+            const uint32_t y4 = tiles32[k * (kTileBytes / 4) + 4 * r + (q & 3)];
+            if (Y) *reinterpret_cast<uint32_t*>(Y + size_t(py) * ystride + px) = y4;
+            if (dst && py < height && px < width) {
+                const int ci = k * (kTileBytes / 2) + 4 * (r >> 1) + (c4 >> 2);       // 16-bit index of the two chroma samples
+                const uint32_t u2 = tiles16[ci + kTileCb / 2], v2 = tiles16[ci + kTileCr / 2];
+                const int npx = min(4, width - px);
+                const size_t pix = size_t(py) * width + px;
+                uint32_t a4 = 0xffffffffu;
+                if (A) {
+                    a4 = 0;
+                    for (int j = 0; j < npx; ++j) a4 |= uint32_t(A[pix + j]) << (8 * j);
+                }
+                const uint4 o = convert_px4(y4, u2, v2, a4);
+                uint8_t* p = dst + pix * 4;
+                if (npx == 4 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                    *reinterpret_cast<uint4*>(p) = o;
+                } else {
+                    const uint32_t ov[4] = {o.x, o.y, o.z, o.w};
+                    for (int j = 0; j < npx; ++j) reinterpret_cast<uint32_t*>(p)[j] = ov[j];
+                }
+            }
+        }
+    }
+    // ---- chroma rows: 2 planes x 8 rows x (16 tiles x 2 dwords) ----
+    if (Up && Vp) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = t + 256 * it;
+            const int plane = idx >> 8, row = (idx >> 5) & 7, dw = idx & 31, kk = dw >> 1, half = dw & 1;
+            const int cy = 8 * ty - (shift >> 1) + row, cx = 8 * (tx0 + kk) - (shift >> 1) + 4 * half;
+            if (kk < nt && cy >= 0 && cx >= 0 && cy < 8 * mbh && cx < cstride) {
+                uint8_t* P = plane ? Vp + fr.v_off : Up + fr.u_off;
+                *reinterpret_cast<uint32_t*>(P + size_t(cy) * cstride + cx) = tiles32[kk * (kTileBytes / 4) + (kTileCb / 4) + 16 * plane + 2 * row + half];
+            }
+        }
+    }
+}
+
+// Row-major planes -> R tiles (only used by the stand-alone loop-filter entry point).
+__global__ __launch_bounds__(256)
+void vp8_tile_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* __restrict__ Yp, const uint8_t* __restrict__ Up,
+                     const uint8_t* __restrict__ Vp, uint8_t* Rp) {
+    const wp_vp8_frame& fr = frames[blockIdx.y];
+    const int mbw = fr.mbw, n_mb = fr.mbw * fr.mbh;
+    const int t = threadIdx.x, j = t & 31;
+    for (int m = blockIdx.x * 8 + (t >> 5); m < n_mb; m += gridDim.x * 8) {
+        const int x = m % mbw, y = m / mbw;
+        uint8_t* tile = Rp + (size_t(fr.mb_base) + m) * kTileBytes;
+        if (j < 16) {
+            *reinterpret_cast<uint4*>(tile + 16 * j) = *reinterpret_cast<const uint4*>(Yp + fr.y_off + size_t(16 * y + j) * (16 * mbw) + 16 * x);
+        } else {
+            const int p = (j - 16) >> 3, r = (j - 16) & 7;
+            const uint8_t* P = p ? Vp + fr.v_off : Up + fr.u_off;
+            *reinterpret_cast<uint2*>(tile + kTileCb + 64 * p + 8 * r) = *reinterpret_cast<const uint2*>(P + size_t(8 * y + r) * (8 * mbw) + 8 * x);
+        }
+    }
+}
+
+}  // namespace wpk
+
+extern "C" int wpk_launch_vp8_finish(int n, int chunks, int tile_rows, const wp_vp8_frame* d_frames, const uint8_t* d_rtiles,
+                                     const uint8_t* d_stiles, int force_unshifted, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
+                                     const uint8_t* d_alpha, uint8_t* d_argb, hipStream_t stream) {
+    hipLaunchKernelGGL(wpk::vp8_finish_kernel, dim3(chunks, tile_rows, n), dim3(256), 0, stream,
+                       d_frames, d_rtiles, d_stiles, force_unshifted, d_y, d_u, d_v, d_alpha, d_argb);
+    return int(hipGetLastError());
+}
+
+extern "C" int wpk_launch_vp8_tile(int n, int grid_x, const wp_vp8_frame* d_frames, const uint8_t* d_y, const uint8_t* d_u,
+                                   const uint8_t* d_v, uint8_t* d_rtiles, hipStream_t stream) {
+    hipLaunchKernelGGL(wpk::vp8_tile_kernel, dim3(grid_x, n), dim3(256), 0, stream, d_frames, d_y, d_u, d_v, d_rtiles);
+    return int(hipGetLastError());
+}

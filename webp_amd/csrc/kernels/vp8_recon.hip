@@ -11,8 +11,9 @@
 // with the same geometry as the reference's `ybr` workspace (Reconstruct.hx:3-12), which keeps the
 // border rules (0x7f / 0x81 fills, top-right replication, the rows-4/8/12 top-right copy) literal.
 // Bands of one frame are pipelined across the wavefronts of a workgroup: the band below waits on
-// an LDS progress word and reads the bottom row of the band above from the output planes
-// (workgroup-scope release/acquire, same CU).
+// an LDS progress word and reads the bottom row of the band above from the output tiles
+// (workgroup-scope release/acquire, same CU).  Output goes to the macroblock-tiled workspace
+// (wp_device.h): one 16-byte luma row + 8-byte chroma row per lane, 384 contiguous bytes per group.
 #include "wp_device.h"
 
 namespace wpk {
@@ -218,7 +219,7 @@ __device__ __forceinline__ int group_sum16(int v) {
 
 __global__ __launch_bounds__(kWavesPerWG * kWave)
 void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, const uint4* __restrict__ mb,
-                      const int16_t* __restrict__ coeff, uint8_t* Yp, uint8_t* Up, uint8_t* Vp) {
+                      const int16_t* __restrict__ coeff, uint8_t* Rp) {
     __shared__ ReconWaveLds lds_all[kWavesPerWG];
     __shared__ uint32_t progress[kWavesPerWG];
 
@@ -237,10 +238,7 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
     for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
         const wp_vp8_frame fr = frames[f];
         const int mbw = fr.mbw, mbh = fr.mbh;
-        const int ystride = 16 * mbw, cstride = 8 * mbw;
-        uint8_t* const Y = Yp + fr.y_off;
-        uint8_t* const U = Up + fr.u_off;
-        uint8_t* const V = Vp + fr.v_off;
+        uint8_t* const R = Rp + size_t(fr.mb_base) * kTileBytes;      // this frame's R tiles
         const int n_bands = (mbh + kBandRows - 1) / kBandRows;
 
         for (int band = 0; band < n_bands; ++band) {
@@ -268,19 +266,18 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                 const uint4 rec = act ? rec_next : make_uint4(0, 0, 0, 0);
                 if (row_ok && x + 1 >= 0 && x + 1 < mbw) rec_next = mb_row[x + 1];
 
-                // ---- top context of group 0 comes from the band above, through the output planes: issue the
+                // ---- top context of group 0 comes from the band above, through the output tiles: issue the
                 //      loads now, park them in the LDS ring after the residuals have been computed ----
                 uint32_t top_a = 0, top_b = 0;
                 const bool fetch_top = has_above && s < mbw && g == 0 && l < 8;
                 if (has_above && s < mbw) {
                     wait_progress(&progress[prev_wave], ((q - 1) << kSeqShift) | uint32_t(min(s + 2, mbw)));
                     if (fetch_top) {
-                        const uint8_t* src0 = l < 4 ? Y + size_t(16 * y - 1) * ystride + 4 * l
-                                            : l < 6 ? U + size_t(8 * y - 1) * cstride + 4 * (l - 4)
-                                                    : V + size_t(8 * y - 1) * cstride + 4 * (l - 6);
-                        const int colbytes = l < 4 ? 16 : 8;
+                        // last luma row / last Cb row / last Cr row of the tile of MB (s+1, y-1)
+                        const uint8_t* src0 = R + size_t(y - 1) * mbw * kTileBytes
+                                            + (l < 4 ? 240 + 4 * l : l < 6 ? kTileCb + 56 + 4 * (l - 4) : kTileCr + 56 + 4 * (l - 6));
                         if (s == 0) top_a = *reinterpret_cast<const uint32_t*>(src0);
-                        if (s + 1 < mbw) top_b = *reinterpret_cast<const uint32_t*>(src0 + size_t(s + 1) * colbytes);
+                        if (s + 1 < mbw) top_b = *reinterpret_cast<const uint32_t*>(src0 + size_t(s + 1) * kTileBytes);
                     }
                 }
 
@@ -319,7 +316,6 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                 }
                 __builtin_amdgcn_wave_barrier();
 
-                uint32_t px[4] = {0, 0, 0, 0}, cpx[4] = {0, 0, 0, 0};
                 if (act) {
                     // ---- prepareYBR (Vp8Decoder.hx:541-577): left column, then top row ----
                     {
@@ -365,8 +361,7 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                         pred_large(mode, top4, left4, int(T.y[0][3]), dcv, pr);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            px[r] = add_clip_row(pr[r], ev[r], od[r]);
-                            tile32(T.y[4 * bj + 1 + r], 4 + 4 * bi) = px[r];
+                            tile32(T.y[4 * bj + 1 + r], 4 + 4 * bi) = add_clip_row(pr[r], ev[r], od[r]);
                         }
                     }
                 }
@@ -387,8 +382,7 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                             pred4x4(mode4, top_lo, top_hi, left4, corner, pr);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                px[r] = add_clip_row(pr[r], ev[r], od[r]);
-                                tile32(T.y[4 * bj + 1 + r], 4 + 4 * bi) = px[r];
+                                tile32(T.y[4 * bj + 1 + r], 4 + 4 * bi) = add_clip_row(pr[r], ev[r], od[r]);
                             }
                         }
                         __builtin_amdgcn_wave_barrier();
@@ -416,8 +410,7 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                         pred_large(c8, top4, left4, int(T.c[0][cb - 1]), dcv, pr);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            cpx[r] = add_clip_row(pr[r], cev[r], cod[r]);
-                            tile32(T.c[4 * cj + 1 + r], cb + 4 * ci) = cpx[r];
+                            tile32(T.c[4 * cj + 1 + r], cb + 4 * ci) = add_clip_row(pr[r], cev[r], cod[r]);
                         }
                     }
                 }
@@ -430,18 +423,17 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                     const int done = s - 2 * (kBandRows - 1) + 1;
                     pending_publish = done >= 1 ? ((q << kSeqShift) | uint32_t(done)) : 0u;
                 }
+                __builtin_amdgcn_wave_barrier();
                 if (act) {
-                    // ---- write back (Vp8Decoder.hx:812-821) ----
-                    const int plane = l >> 3;
-                    uint8_t* yd = Y + size_t(16 * y + 4 * bj) * ystride + 16 * x + 4 * bi;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) *reinterpret_cast<uint32_t*>(yd + size_t(r) * ystride) = px[r];
-                    if (chroma_lane) {
-                        const int cj = (l >> 1) & 1, ci = l & 1;
-                        uint8_t* cd = (plane ? V : U) + size_t(8 * y + 4 * cj) * cstride + 8 * x + 4 * ci;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) *reinterpret_cast<uint32_t*>(cd + size_t(r) * cstride) = cpx[r];
-                    }
+                    // ---- write back (Vp8Decoder.hx:812-821): the MB sits complete in the LDS tile; lane l stores
+                    //      luma row l and one chroma row, so the group emits the 384-byte tile as three full lines ----
+                    uint8_t* tile = R + (size_t(y) * mbw + x) * kTileBytes;
+                    const uint8_t* yr = T.y[1 + l];
+                    *reinterpret_cast<uint4*>(tile + 16 * l) = make_uint4(tile32(const_cast<uint8_t*>(yr), 4), tile32(const_cast<uint8_t*>(yr), 8),
+                                                                          tile32(const_cast<uint8_t*>(yr), 12), tile32(const_cast<uint8_t*>(yr), 16));
+                    uint8_t* cr = T.c[1 + (l & 7)];
+                    const int cc = (l >> 3) ? 20 : 4;
+                    *reinterpret_cast<uint2*>(tile + kTileCb + 8 * l) = make_uint2(tile32(cr, cc), tile32(cr, cc + 4));
                 }
                 __builtin_amdgcn_wave_barrier();
                 // ---- hand the bottom row to the group below (same wavefront, two steps later) ----
@@ -461,8 +453,8 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
 }  // namespace wpk
 
 extern "C" int wpk_launch_vp8_recon(int n, int grid, const wp_vp8_frame* d_frames, const void* d_mb, const int16_t* d_coeff,
-                                    uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, hipStream_t stream) {
+                                    uint8_t* d_rtiles, hipStream_t stream) {
     hipLaunchKernelGGL(wpk::vp8_recon_kernel, dim3(grid), dim3(wpk::kWavesPerWG * wpk::kWave), 0, stream,
-                       n, d_frames, reinterpret_cast<const uint4*>(d_mb), d_coeff, d_y, d_u, d_v);
+                       n, d_frames, reinterpret_cast<const uint4*>(d_mb), d_coeff, d_rtiles);
     return int(hipGetLastError());
 }

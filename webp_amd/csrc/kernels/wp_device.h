@@ -12,6 +12,18 @@ constexpr int kWavesPerWG = 8;        // wavefronts per workgroup in the wavefro
 constexpr uint32_t kSeqShift = 12;    // progress word = (band sequence << 12) | macroblocks finished
 constexpr uint32_t kBandDone = 0xFFF;
 
+// Macroblock-tiled intermediate layout (workspace between recon, loop filter and the finishing pass).
+// One tile = 384 contiguous bytes = three 128-byte lines: 16 luma rows of 16 bytes, 8 Cb rows of 8, 8 Cr rows of 8.
+//   R tiles (recon output):        tile (x, y) of a frame at index mb_base + y*mbw + x, holds macroblock (x, y).
+//   S tiles (loop-filter output):  grid (mbw+1) x (mbh+1) at index stile_base + ty*(mbw+1) + tx; tile (tx, ty) holds
+//                                  luma rows 16ty-8..16ty+7 / cols 16tx-8..16tx+7 and chroma rows 8ty-4..8ty+3 / cols
+//                                  8tx-4..8tx+3: the region that is FINAL once macroblock (tx, ty) has been filtered.
+// Every wavefront-scheduled kernel reads and writes whole tiles (full cache lines); only the streaming finishing
+// pass touches the row-major planes / ARGB, with long contiguous rows.
+constexpr int kTileBytes = 384;
+constexpr int kTileCb = 256, kTileCr = 320;
+constexpr int kFiltShift = 8;         // luma shift of the S grid (chroma: 4)
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }   // -> v_med3_i32
 
 // Cross-wavefront hand-over inside a workgroup (all its wavefronts run on one CU and share its L1):

@@ -23,6 +23,10 @@ class DeviceLossyBatch:
         self.b = batch
         self.device = torch.device(device)
         lib().wp_init(self.device.index or 0)
+        work_bytes = ctypes.c_uint64(0)
+        check(lib().wp_vp8_plan(batch.n, batch.desc, ctypes.byref(work_bytes)))      # fills stile_base before the upload
+        self.work_bytes = int(work_bytes.value)
+        self.work = torch.empty(max(self.work_bytes, 256), dtype=torch.uint8, device=self.device)   # torch allocations are >= 256-B aligned
         self.frames = _dev(np.frombuffer(bytes(batch.desc), dtype=np.uint8)[:ctypes.sizeof(Vp8Frame) * max(batch.n, 1)], self.device)
         self.mb = _dev(batch.mb, self.device)
         self.filt = _dev(batch.filt, self.device)
@@ -36,24 +40,34 @@ class DeviceLossyBatch:
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def recon(self):
-        check(lib().wp_vp8_recon_dev(self.b.n, self.b.desc, self.frames.data_ptr(), self.mb.data_ptr(), self.coeff.data_ptr(),
-                                     self.y.data_ptr(), self.u.data_ptr(), self.v.data_ptr(), self._stream()))
+    def _planes(self, on):
+        return (self.y.data_ptr(), self.u.data_ptr(), self.v.data_ptr()) if on else (None, None, None)
 
-    def loopfilter(self):
+    def _alpha(self):
+        return self.alpha.data_ptr() if self.alpha is not None else None
+
+    def recon(self, planes=True):
+        """Reconstruction into the tiled workspace; planes=True also writes the unfiltered row-major planes."""
+        check(lib().wp_vp8_recon_dev(self.b.n, self.b.desc, self.frames.data_ptr(), self.mb.data_ptr(), self.coeff.data_ptr(),
+                                     self.work.data_ptr(), self.work_bytes, *self._planes(planes), self._stream()))
+
+    def loopfilter(self, planes=True):
+        """planes=True: filter the row-major planes in place; planes=False: workspace R tiles -> S tiles."""
         check(lib().wp_vp8_loopfilter_dev(self.b.n, self.b.desc, self.frames.data_ptr(), self.filt.data_ptr(),
-                                          self.y.data_ptr(), self.u.data_ptr(), self.v.data_ptr(), self._stream()))
+                                          self.work.data_ptr(), self.work_bytes, *self._planes(planes), self._stream()))
+
+    def finish(self, planes=True, argb=True):
+        check(lib().wp_vp8_finish_dev(self.b.n, self.b.desc, self.frames.data_ptr(), self.work.data_ptr(), self.work_bytes,
+                                      *self._planes(planes), self._alpha(), self.argb.data_ptr() if argb else None, self._stream()))
 
     def convert(self):
         check(lib().wp_yuv420_to_argb_dev(self.b.n, self.b.desc, self.frames.data_ptr(), self.y.data_ptr(), self.u.data_ptr(),
-                                          self.v.data_ptr(), self.alpha.data_ptr() if self.alpha is not None else None,
-                                          self.argb.data_ptr(), self._stream()))
+                                          self.v.data_ptr(), self._alpha(), self.argb.data_ptr(), self._stream()))
 
-    def decode_to_argb(self):
+    def decode_to_argb(self, planes=True):
         check(lib().wp_vp8_decode_to_argb_dev(self.b.n, self.b.desc, self.frames.data_ptr(), self.mb.data_ptr(), self.filt.data_ptr(),
-                                              self.coeff.data_ptr(), self.y.data_ptr(), self.u.data_ptr(), self.v.data_ptr(),
-                                              self.alpha.data_ptr() if self.alpha is not None else None,
-                                              self.argb.data_ptr(), self._stream()))
+                                              self.coeff.data_ptr(), self.work.data_ptr(), self.work_bytes, *self._planes(planes),
+                                              self._alpha(), self.argb.data_ptr(), self._stream()))
 
     # ---- readback helpers (tests) ----
     def planes(self, i):
