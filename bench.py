@@ -132,7 +132,7 @@ def main():
 
     line = {"metric": "decoded Mpix/s (whole node) for batched 1080p lossy WebP", "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32/u8 (+f64 colour conversion)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32/u8",
             "data": "synthetic",
             "config": {"workload": "%d x 1920x1080 VP8 lossy (libwebp: 8 x q75 m4 normal filter + q90 + q50 sharp3 + simple-filter variant) per GPU: recon + loop filter + "
                                    "finishing pass (YUV420 planes + ARGB out), inputs resident in HBM" % args.images,

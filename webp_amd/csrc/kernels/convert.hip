@@ -1,11 +1,8 @@
 // YUV420 (macroblock-padded planes) -> tightly packed A,R,G,B.  Replaces Tools.toArgb (Tools.hx:6-48).
 //
-// The reference converts in double precision, full range, nearest chroma sample, then
-// Math.round(Math.max(0, Math.min(255, x))) with Math.round = floor(x + 0.5).  The kernel
-// does the same operations in the same order in fp64 with explicitly rounded (non-fused)
-// multiplies and adds, so the result is bit-identical for every (Y, Cb, Cr) triple; the GPU test
-// checks all 2^24 of them.  Pure streaming: each thread converts 4 horizontally adjacent pixels
-// (one dword of luma, two chroma samples) and stores 16 bytes.
+// The arithmetic (an integer form that is bit-identical to the reference's fp64 expressions for every
+// (Y, Cb, Cr) triple) is in wp_convert.h.  Pure streaming: each thread converts 4 horizontally adjacent
+// pixels (one dword of luma, two chroma samples) and stores 16 bytes.
 #include "wp_device.h"
 #include "wp_convert.h"
 
@@ -38,13 +35,11 @@ void yuv420_to_argb_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_
             a4 = 0;
             for (int k = 0; k < npx; ++k) a4 |= uint32_t(A[pix + k]) << (8 * k);
         }
-        uint32_t o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            o[k] = convert_px(int((y4 >> (8 * k)) & 0xff), int((u2 >> (8 * (k >> 1))) & 0xff), int((v2 >> (8 * (k >> 1))) & 0xff), (a4 >> (8 * k)) & 0xff);
+        const uint4 o4 = convert_px4(y4, u2, v2, a4);
+        const uint32_t o[4] = {o4.x, o4.y, o4.z, o4.w};
         uint8_t* p = dst + pix * 4;
         if (npx == 4 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-            *reinterpret_cast<uint4*>(p) = make_uint4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<uint4*>(p) = o4;
         } else {
             for (int k = 0; k < npx; ++k) reinterpret_cast<uint32_t*>(p)[k] = o[k];
         }

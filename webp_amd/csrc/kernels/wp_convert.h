@@ -1,30 +1,45 @@
 // Per-pixel YUV -> ARGB arithmetic shared by the streaming conversion kernels (Tools.hx:25-31).
+//
+// The reference converts in double precision, full range:  R = Y + 1.402 Cr,  G = Y - 0.344136 Cb - 0.714136 Cr,
+// B = Y + 1.772 Cb  (Cb, Cr centred on 128), then Math.round(clamp(x, 0, 255)) with Math.round = floor(x + 0.5)
+// (SURVEY Q7).  Every chroma term is an integer divided by 1000 (R, B) or 10^6 (G), so x is within ~1e-13 of a
+// rational whose distance to the next rounding boundary is either 0 (an exact .5 tie) or >= 1e-6: only at exact
+// ties can fp64 rounding error change the result.  Enumerating them:
+//   R: 1402 Cr = 500 (mod 1000) has no solution in -128..127.
+//   B: Cb = +-125; fp64 rounds both like round-half-up.
+//   G: (Cb, Cr) = (-50, 50) and (50, -50); fp64 rounds like round-half-up except (-50, 50) with 111 <= Y <= 146,
+//      where (Y - a) - b lands one ulp below the tie (result Y - 19 instead of Y - 18).
+// Hence the integer form below is bit-identical to the reference's fp64 arithmetic for all 2^24 (Y, Cb, Cr)
+// triples; the GPU test checks every one of them against the fp64 oracle.  round(clamp(x)) = clamp(round(x)).
 #pragma once
 #include "wp_device.h"
 
 namespace wpk {
 
-__device__ __forceinline__ uint32_t round255(double x) {
-    x = fmax(0.0, fmin(255.0, x));
-    return uint32_t(int(floor(__dadd_rn(x, 0.5))));
+// rounded chroma contributions of one (Cb, Cr) sample, shared by the 2x2 luma samples it covers
+struct ChromaTerms { int r, g, b; bool tie; };
+__device__ __forceinline__ ChromaTerms chroma_terms(int cbv, int crv) {
+    const int cb = cbv - 128, cr = crv - 128;
+    ChromaTerms t;
+    t.r = (5743 * cr + 2048) >> 12;                                                        // floor(1.402 cr + 0.5)
+    t.b = int(uint32_t(1772 * cb + 500 + 1000000) / 1000u) - 1000;                         // floor(1.772 cb + 0.5)
+    t.g = int(uint32_t(500000 - 344136 * cb - 714136 * cr + 200000000) / 1000000u) - 200;  // floor(0.5 - 0.344136 cb - 0.714136 cr)
+    t.tie = cb == -50 && cr == 50;
+    return t;
 }
 
 // one pixel -> bytes A,R,G,B in memory order (little-endian dword: A | R<<8 | G<<16 | B<<24)
-__device__ __forceinline__ uint32_t convert_px(int yv, int cb, int cr, uint32_t a) {
-    const double Yd = double(yv), Cb = double(cb - 128), Cr = double(cr - 128);
-    const double R = __dadd_rn(Yd, __dmul_rn(1.402, Cr));
-    const double G = __dsub_rn(__dsub_rn(Yd, __dmul_rn(0.344136, Cb)), __dmul_rn(0.714136, Cr));
-    const double B = __dadd_rn(Yd, __dmul_rn(1.772, Cb));
-    return a | round255(R) << 8 | round255(G) << 16 | round255(B) << 24;
+__device__ __forceinline__ uint32_t convert_px(int yv, const ChromaTerms& t, uint32_t a) {
+    const int fix = (t.tie && yv >= 111 && yv <= 146) ? 1 : 0;
+    return a | uint32_t(clampi(yv + t.r, 0, 255)) << 8 | uint32_t(clampi(yv + t.g - fix, 0, 255)) << 16 | uint32_t(clampi(yv + t.b, 0, 255)) << 24;
 }
 
 // four horizontally adjacent pixels: luma dword, two chroma samples each, four alpha bytes -> 16 bytes of A,R,G,B
 __device__ __forceinline__ uint4 convert_px4(uint32_t y4, uint32_t u2, uint32_t v2, uint32_t a4) {
-    uint32_t o[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        o[k] = convert_px(int((y4 >> (8 * k)) & 0xff), int((u2 >> (8 * (k >> 1))) & 0xff), int((v2 >> (8 * (k >> 1))) & 0xff), (a4 >> (8 * k)) & 0xff);
-    return make_uint4(o[0], o[1], o[2], o[3]);
+    const ChromaTerms t0 = chroma_terms(int(u2 & 0xff), int(v2 & 0xff));
+    const ChromaTerms t1 = chroma_terms(int((u2 >> 8) & 0xff), int((v2 >> 8) & 0xff));
+    return make_uint4(convert_px(int(y4 & 0xff), t0, a4 & 0xff), convert_px(int((y4 >> 8) & 0xff), t0, (a4 >> 8) & 0xff),
+                      convert_px(int((y4 >> 16) & 0xff), t1, (a4 >> 16) & 0xff), convert_px(int(y4 >> 24), t1, a4 >> 24));
 }
 
 }  // namespace wpk
