@@ -91,7 +91,7 @@ struct FinishGeom { int chunks = 1, rows = 1; };
 FinishGeom finish_geom(int n, const wp_vp8_frame* f) {
     FinishGeom g;
     for (int i = 0; i < n; ++i) {
-        g.chunks = std::max(g.chunks, (f[i].mbw + 1 + 15) / 16);
+        g.chunks = std::max(g.chunks, (f[i].mbw + 15) / 16);      // 256 output columns per workgroup
         g.rows = std::max(g.rows, f[i].mbh + 1);
     }
     return g;

@@ -2,16 +2,18 @@
 // ImageData.Yuv420 carries, Vp8Decoder.ensureImg geometry) and tightly packed A,R,G,B (Tools.toArgb,
 // Tools.hx:6-48), plus the inverse helper that tiles row-major planes for the stand-alone loop filter.
 //
-// Pure streaming.  A workgroup takes up to 16 horizontally adjacent tiles (6 KB, contiguous in memory),
-// parks them in LDS and writes rows: a wavefront emits 1 KB of contiguous ARGB (256 pixels of one row),
-// 256 B of luma or 128 B of chroma per instruction.  Frames whose loop filter is off are read from the
+// Pure streaming.  A workgroup produces 256 output columns x 16 rows: it parks the 16 (or, for shifted tiles,
+// 17) horizontally adjacent source tiles (6.4 KB, contiguous in memory) in LDS and writes rows: a wavefront emits
+// 1 KB of contiguous ARGB (256 pixels of one row), 256 B of luma or 128 B of chroma per instruction, all starting
+// on 128-byte boundaries of the row (no cache line is shared between workgroups).  Frames whose loop filter is off are read from the
 // R tiles (no shift), all others from the S tiles (shift 8 luma / 4 chroma).
 #include "wp_device.h"
 #include "wp_convert.h"
 
 namespace wpk {
 
-constexpr int kFinishTiles = 16;
+constexpr int kFinishCols = 256;                       // output luma columns per workgroup
+constexpr int kFinishTiles = kFinishCols / 16 + 1;      // source tiles that can overlap them
 
 __global__ __launch_bounds__(256)
 void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* __restrict__ Rp, const uint8_t* __restrict__ Sp,
@@ -22,9 +24,10 @@ void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* _
     const bool shifted = fr.filter_type != 0 && !force_unshifted;
     const int shift = shifted ? kFiltShift : 0;
     const int ntx = mbw + (shifted ? 1 : 0), nty = mbh + (shifted ? 1 : 0);
-    const int ty = blockIdx.y, tx0 = blockIdx.x * kFinishTiles;
-    if (ty >= nty || tx0 >= ntx) return;
-    const int nt = min(kFinishTiles, ntx - tx0);
+    const int ty = blockIdx.y, c0 = blockIdx.x * kFinishCols;     // output columns c0 .. c0+255
+    if (ty >= nty || c0 >= 16 * mbw) return;
+    const int tx0 = c0 >> 4;                                      // (c0 + shift) >> 4: first source tile
+    const int nt = min(shifted ? kFinishTiles : kFinishTiles - 1, ntx - tx0);
     const uint8_t* src = (shifted ? Sp + size_t(fr.stile_base) * kTileBytes : Rp + size_t(fr.mb_base) * kTileBytes)
                        + (size_t(ty) * ntx + tx0) * kTileBytes;
     const int t = threadIdx.x;
@@ -39,15 +42,15 @@ void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* _
     uint8_t* const dst = out ? out + fr.argb_off : nullptr;
 
     // ---- luma rows + ARGB: thread = 4 pixels, wavefront = 256 pixels of one row ----
-    const int q = t & 63, k = q >> 2, c4 = (q & 3) * 4;
-    const int px = 16 * (tx0 + k) - shift + c4;
-    if (k < nt && px >= 0 && px < ystride) {
+    const int q = t & 63, px = c0 + 4 * q;
+    const int k = (4 * q + shift) >> 4, c4 = (4 * q + shift) & 15;         // source tile / column inside it
+    if (k < nt && px < ystride) {
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             const int r = pass * 4 + (t >> 6);
             const int py = 16 * ty - shift + r;
             if (py < 0 || py >= 16 * mbh) continue;
-            const uint32_t y4 = tiles32[k * (kTileBytes / 4) + 4 * r + (q & 3)];
+            const uint32_t y4 = tiles32[k * (kTileBytes / 4) + 4 * r + (c4 >> 2)];
             if (Y) *reinterpret_cast<uint32_t*>(Y + size_t(py) * ystride + px) = y4;
             if (dst && py < height && px < width) {
                 const int ci = k * (kTileBytes / 2) + 4 * (r >> 1) + (c4 >> 2);       // 16-bit index of the two chroma samples
@@ -75,9 +78,10 @@ void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* _
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int idx = t + 256 * it;
-            const int plane = idx >> 8, row = (idx >> 5) & 7, dw = idx & 31, kk = dw >> 1, half = dw & 1;
-            const int cy = 8 * ty - (shift >> 1) + row, cx = 8 * (tx0 + kk) - (shift >> 1) + 4 * half;
-            if (kk < nt && cy >= 0 && cx >= 0 && cy < 8 * mbh && cx < cstride) {
+            const int plane = idx >> 8, row = (idx >> 5) & 7, dw = idx & 31;
+            const int cy = 8 * ty - (shift >> 1) + row, cx = (c0 >> 1) + 4 * dw;
+            const int kk = (4 * dw + (shift >> 1)) >> 3, half = ((4 * dw + (shift >> 1)) >> 2) & 1;
+            if (kk < nt && cy >= 0 && cy < 8 * mbh && cx < cstride) {
                 uint8_t* P = plane ? Vp + fr.v_off : Up + fr.u_off;
                 *reinterpret_cast<uint32_t*>(P + size_t(cy) * cstride + cx) = tiles32[kk * (kTileBytes / 4) + (kTileCb / 4) + 16 * plane + 2 * row + half];
             }
