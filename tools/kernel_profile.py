@@ -1,0 +1,21 @@
+"""Per-phase cycle profile of one wavefront (workgroup 0, wave 0) of the recon kernel.
+Needs a -DWP_PROFILE build: WEBP_AMD_LIB=webp_amd/variants/libwebp_amd_prof.so python tools/kernel_profile.py"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from webp_amd._lib import lib
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+files, batch, db, paths, _ = bench.build_batch(n, "lossy1080_*.webp", "cuda:0")
+L = lib()
+buf = (ctypes.c_ulonglong * 32)()
+db.recon(planes=False); torch.cuda.synchronize()
+L.wp_debug_profile(buf, 1)
+db.recon(planes=False); torch.cuda.synchronize()
+L.wp_debug_profile(buf, 0)
+names = ["0 wait+top loads", "1 residuals", "2 tile prep", "3 i16", "4 i4 loop", "5 chroma", "6 publish+store", "7 band end", "8 loop top", "9 band start"]
+tot = sum(buf[i] for i in range(10))
+for i, nm in enumerate(names):
+    print("%-18s %12d  %5.1f%%" % (nm, buf[i], 100.0 * buf[i] / max(tot, 1)))
+print("total cycles", tot)

@@ -26,3 +26,5 @@ print("finish argb only %.3f ms" % t(lambda: db.finish(False, True)))
 print("finish planes    %.3f ms" % t(lambda: db.finish(True, False)))
 print("convert (linear) %.3f ms" % t(lambda: db.convert()))
 print("fused            %.3f ms" % t(lambda: db.decode_to_argb()))
+db.argb.zero_(); db.decode_to_argb(); torch.cuda.synchronize()
+print("checksum argb %d  y %d" % (int(db.argb[::4099].to(torch.int64).sum()), int(db.y[::4099].to(torch.int64).sum())))

@@ -5,7 +5,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libwebp_amd.so")
+SO_PATH = os.environ.get("WEBP_AMD_LIB") or os.path.join(_HERE, "libwebp_amd.so")   # override: tuning variants only
 
 c_u8p = ctypes.POINTER(ctypes.c_uint8)
 

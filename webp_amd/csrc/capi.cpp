@@ -11,9 +11,9 @@
 
 // kernel launchers (kernels/*.hip)
 extern "C" {
-int wpk_launch_vp8_recon(int n, int grid, const wp_vp8_frame* d_frames, const void* d_mb, const int16_t* d_coeff,
+int wpk_launch_vp8_recon(int n, int cus, const wp_vp8_frame* d_frames, const void* d_mb, const int16_t* d_coeff,
                          uint8_t* d_rtiles, hipStream_t stream);
-int wpk_launch_vp8_filter(int n, int grid, const wp_vp8_frame* d_frames, const uint32_t* d_filt,
+int wpk_launch_vp8_filter(int n, int cus, const wp_vp8_frame* d_frames, const uint32_t* d_filt,
                           const uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream);
 int wpk_launch_vp8_finish(int n, int chunks, int tile_rows, const wp_vp8_frame* d_frames, const uint8_t* d_rtiles,
                           const uint8_t* d_stiles, int force_unshifted, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
@@ -31,7 +31,6 @@ int wpk_launch_alpha(int n, const wp_alpha_frame* frames_host, const wp_alpha_fr
 namespace {
 
 thread_local std::string g_error;
-int g_wavefront_grid = 0;      // workgroups for the wavefront-scheduled kernels (set by wp_init)
 int g_cus = 0;
 
 int fail(int code, const std::string& msg) { g_error = msg; return code; }
@@ -135,7 +134,6 @@ int wp_init(int device) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     g_cus = prop.multiProcessorCount;
-    g_wavefront_grid = g_cus * 2;      // 2 workgroups of 8 wavefronts per CU (LDS and VGPR budget allow it)
     return WP_OK;
 }
 
@@ -170,8 +168,7 @@ int wp_vp8_recon_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, cons
     Vp8Work w;
     rc = check_vp8_work(n, fh, d_work, work_bytes, w); if (rc) return rc;
     uint8_t* work = static_cast<uint8_t*>(d_work);
-    const int grid = std::min(n, g_wavefront_grid);
-    const int e = wpk_launch_vp8_recon(n, grid, fd, d_mb, d_coeff, work, hipStream_t(stream));
+    const int e = wpk_launch_vp8_recon(n, g_cus, fd, d_mb, d_coeff, work, hipStream_t(stream));
     if (e) return hip_fail(hipError_t(e), "vp8_recon launch");
     if (planes) return launch_finish(n, fh, fd, work, w, 1, d_y, d_u, d_v, nullptr, nullptr, hipStream_t(stream));
     return WP_OK;
@@ -198,8 +195,7 @@ int wp_vp8_loopfilter_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd,
             if (e) return hip_fail(hipError_t(e), "vp8_tile launch");
         }
     }
-    const int grid = std::min(n, g_wavefront_grid);
-    const int e = wpk_launch_vp8_filter(n, grid, fd, d_filt, work, work + w.r_bytes, hipStream_t(stream));
+    const int e = wpk_launch_vp8_filter(n, g_cus, fd, d_filt, work, work + w.r_bytes, hipStream_t(stream));
     if (e) return hip_fail(hipError_t(e), "vp8_filter launch");
     if (planes) return launch_finish(n, fh, fd, work, w, 0, d_y, d_u, d_v, nullptr, nullptr, hipStream_t(stream));
     return WP_OK;

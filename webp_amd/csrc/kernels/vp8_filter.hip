@@ -118,11 +118,21 @@ __device__ __forceinline__ void filter_line(int (&v)[N], bool simple, bool mb_ed
     }
 }
 
-__global__ __launch_bounds__(kWavesPerWG * kWave)
+// workgroup shape and occupancy target: waves per workgroup, workgroups per CU (=> waves per SIMD = product / 4)
+#ifndef WP_FILTER_WAVES
+#define WP_FILTER_WAVES 8
+#endif
+#ifndef WP_FILTER_WGS_PER_CU
+#define WP_FILTER_WGS_PER_CU 2
+#endif
+constexpr int kFilterWaves = WP_FILTER_WAVES;
+constexpr int kFilterWGsPerCU = WP_FILTER_WGS_PER_CU;
+
+__global__ __launch_bounds__(kFilterWaves * kWave, (kFilterWaves * kFilterWGsPerCU + 3) / 4)
 void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, const uint32_t* __restrict__ filt,
                        const uint8_t* __restrict__ Rp, uint8_t* Sp) {
-    __shared__ FilterWaveLds lds_all[kWavesPerWG];
-    __shared__ uint32_t progress[kWavesPerWG];
+    __shared__ FilterWaveLds lds_all[kFilterWaves];
+    __shared__ uint32_t progress[kFilterWaves];
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -135,7 +145,7 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
     const int hr = l >> 1, hh = l & 1;                    // hand-over: luma row 0..7, 8-byte half
     const int hcr = (l >> 1) & 3;                         // hand-over: chroma row 0..3 (plane = lp, 4-byte half = hh)
 
-    if (threadIdx.x < kWavesPerWG) progress[threadIdx.x] = 0;
+    if (threadIdx.x < kFilterWaves) progress[threadIdx.x] = 0;
     __syncthreads();
 
     uint32_t seq = 1;
@@ -151,12 +161,12 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
 
         for (int band = 0; band < n_bands; ++band) {
             const uint32_t q = seq + uint32_t(band);
-            if (int(q % kWavesPerWG) != wave) continue;
+            if (int(q % kFilterWaves) != wave) continue;
             const int y = band * kBandRows + g;
             const bool row_ok = y < mbh;
             const bool has_above = band > 0;
             const bool has_below = band + 1 < n_bands;
-            const int prev_wave = (wave + kWavesPerWG - 1) % kWavesPerWG;
+            const int prev_wave = (wave + kFilterWaves - 1) % kFilterWaves;
             const int rows_here = min(kBandRows, mbh - band * kBandRows);
             const int n_steps = mbw + 2 * (rows_here - 1);
             const bool last_row = g == rows_here - 1;             // its bottom rows leave the band through the S tiles
@@ -314,9 +324,10 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
 
 }  // namespace wpk
 
-extern "C" int wpk_launch_vp8_filter(int n, int grid, const wp_vp8_frame* d_frames, const uint32_t* d_filt,
+extern "C" int wpk_launch_vp8_filter(int n, int cus, const wp_vp8_frame* d_frames, const uint32_t* d_filt,
                                      const uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream) {
-    hipLaunchKernelGGL(wpk::vp8_filter_kernel, dim3(grid), dim3(wpk::kWavesPerWG * wpk::kWave), 0, stream,
+    const int grid = n < cus * wpk::kFilterWGsPerCU ? n : cus * wpk::kFilterWGsPerCU;
+    hipLaunchKernelGGL(wpk::vp8_filter_kernel, dim3(grid), dim3(wpk::kFilterWaves * wpk::kWave), 0, stream,
                        n, d_frames, d_filt, d_rtiles, d_stiles);
     return int(hipGetLastError());
 }

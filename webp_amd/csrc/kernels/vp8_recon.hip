@@ -33,10 +33,14 @@ __device__ __forceinline__ uint32_t& tile32(uint8_t* row, int col) { return *rei
 __device__ __forceinline__ int avg3(int a, int b, int c) { return (a + 2 * b + c + 2) >> 2; }
 __device__ __forceinline__ int avg2(int a, int b) { return (a + b + 1) >> 1; }
 __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) { return uint32_t(a) | uint32_t(b) << 8 | uint32_t(c) << 16 | uint32_t(d) << 24; }
+// byte 0 of v in all four bytes (one v_perm_b32; a multiply by 0x01010101 would be a quarter-rate v_mul_lo_u32)
+__device__ __forceinline__ uint32_t splat4(int v) { return __builtin_amdgcn_perm(uint32_t(v), uint32_t(v), 0u); }
 __device__ __forceinline__ int byteof(uint32_t v, int i) { return int((v >> (8 * i)) & 0xff); }
 
-// Wrapping 32-bit multiply, arithmetic >> 16 (Vp8Decoder.hx:913-914).
-__device__ __forceinline__ int mul16(int a, int c) { return int(uint32_t(a) * uint32_t(c)) >> 16; }
+// Wrapping 32-bit multiply, arithmetic >> 16 (Vp8Decoder.hx:913-914).  The operands of every call fit in 24
+// signed bits (coefficients are int16, the WHT DC < 2^18, first-pass outputs < 2^18, the constants < 2^17), so the low
+// 32 bits of the full-rate 24-bit multiply equal the wrapping 32-bit product (v_mul_lo_u32 is quarter rate).
+__device__ __forceinline__ int mul16(int a, int c) { return __mul24(a, c) >> 16; }
 
 typedef short short2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t as_u32(short2_t v) { return __builtin_bit_cast(uint32_t, v); }
@@ -81,10 +85,8 @@ __device__ __forceinline__ uint32_t add_clip_row(uint32_t pred, uint32_t even, u
     return as_u32(lo) | (as_u32(hi) << 8);
 }
 
-// Loads a stored coefficient block (16 x int16, natural order) into ints.
-__device__ __forceinline__ void load_block(const int16_t* p, int (&c)[16]) {
-    const uint4 a = reinterpret_cast<const uint4*>(p)[0];
-    const uint4 b = reinterpret_cast<const uint4*>(p)[1];
+// Unpacks a stored coefficient block (16 x int16, natural order; two 16-byte halves) into ints.
+__device__ __forceinline__ void unpack_block(const uint4& a, const uint4& b, int (&c)[16]) {
     const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
     for (int i = 0; i < 8; ++i) { c[2 * i] = int(int16_t(w[i] & 0xffff)); c[2 * i + 1] = int(w[i]) >> 16; }
@@ -114,7 +116,7 @@ __device__ __forceinline__ void pred4x4(int mode, uint32_t top_lo, uint32_t top_
     switch (mode) {
     case 0: {   // DC
         const int v = (T0 + T1 + T2 + T3 + L0 + L1 + L2 + L3 + 4) >> 3;
-        row[0] = row[1] = row[2] = row[3] = uint32_t(v) * 0x01010101u;
+        row[0] = row[1] = row[2] = row[3] = splat4(v);
         break; }
     case 1: {   // TM
         const int L[4] = {L0, L1, L2, L3};
@@ -129,10 +131,10 @@ __device__ __forceinline__ void pred4x4(int mode, uint32_t top_lo, uint32_t top_
         row[0] = row[1] = row[2] = row[3] = v;
         break; }
     case 3: {   // HE (smoothed)
-        row[0] = uint32_t(avg3(C, L0, L1)) * 0x01010101u;
-        row[1] = uint32_t(avg3(L0, L1, L2)) * 0x01010101u;
-        row[2] = uint32_t(avg3(L1, L2, L3)) * 0x01010101u;
-        row[3] = uint32_t(avg3(L2, L3, L3)) * 0x01010101u;
+        row[0] = splat4(avg3(C, L0, L1));
+        row[1] = splat4(avg3(L0, L1, L2));
+        row[2] = splat4(avg3(L1, L2, L3));
+        row[3] = splat4(avg3(L2, L3, L3));
         break; }
     case 4: {   // RD
         const int srq = avg3(L3, L2, L1), rqp = avg3(L2, L1, L0), qpa = avg3(L1, L0, C), pab = avg3(L0, C, T0);
@@ -202,9 +204,9 @@ __device__ __forceinline__ void pred_large(int mode, uint32_t top4, uint32_t lef
         row[0] = row[1] = row[2] = row[3] = top4;
     } else if (mode == 3) {     // HE
 #pragma unroll
-        for (int r = 0; r < 4; ++r) row[r] = uint32_t(byteof(left4, r)) * 0x01010101u;
+        for (int r = 0; r < 4; ++r) row[r] = splat4(byteof(left4, r));
     } else {                    // DC and its top/left variants
-        row[0] = row[1] = row[2] = row[3] = uint32_t(dcval) * 0x01010101u;
+        row[0] = row[1] = row[2] = row[3] = splat4(dcval);
     }
 }
 
@@ -217,11 +219,21 @@ __device__ __forceinline__ int group_sum16(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(kWavesPerWG * kWave)
+// workgroup shape and occupancy target: waves per workgroup, workgroups per CU (=> waves per SIMD = product / 4)
+#ifndef WP_RECON_WAVES
+#define WP_RECON_WAVES 8
+#endif
+#ifndef WP_RECON_WGS_PER_CU
+#define WP_RECON_WGS_PER_CU 2
+#endif
+constexpr int kReconWaves = WP_RECON_WAVES;
+constexpr int kReconWGsPerCU = WP_RECON_WGS_PER_CU;
+
+__global__ __launch_bounds__(kReconWaves * kWave, (kReconWaves * kReconWGsPerCU + 3) / 4)
 void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, const uint4* __restrict__ mb,
                       const int16_t* __restrict__ coeff, uint8_t* Rp) {
-    __shared__ ReconWaveLds lds_all[kWavesPerWG];
-    __shared__ uint32_t progress[kWavesPerWG];
+    __shared__ ReconWaveLds lds_all[kReconWaves];
+    __shared__ uint32_t progress[kReconWaves];
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -231,10 +243,11 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
     ReconWaveLds& lds = lds_all[wave];
     ReconTile& T = lds.tile[g];
 
-    if (threadIdx.x < kWavesPerWG) progress[threadIdx.x] = 0;
+    if (threadIdx.x < kReconWaves) progress[threadIdx.x] = 0;
     __syncthreads();
 
     uint32_t seq = 1;                   // running band number of this workgroup (identical in all its waves)
+    WP_PROF_DECL;
     for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
         const wp_vp8_frame fr = frames[f];
         const int mbw = fr.mbw, mbh = fr.mbh;
@@ -243,28 +256,54 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
 
         for (int band = 0; band < n_bands; ++band) {
             const uint32_t q = seq + uint32_t(band);
-            if (int(q % kWavesPerWG) != wave) continue;
+            if (int(q % kReconWaves) != wave) continue;
             const int y = band * kBandRows + g;
             const bool row_ok = y < mbh;
             const bool has_above = band > 0;
             const bool has_below = band + 1 < n_bands;
-            const int prev_wave = (wave + kWavesPerWG - 1) % kWavesPerWG;
+            const int prev_wave = (wave + kReconWaves - 1) % kReconWaves;
             const int rows_here = min(kBandRows, mbh - band * kBandRows);
             const int n_steps = mbw + 2 * (rows_here - 1);
 
-            // The MB record is fetched one step ahead so that the coefficient addresses are known as soon as a
-            // step starts (two dependent global round trips would otherwise sit on every step's critical path).
+            // No global round trip sits on a step's critical path: the MB record is fetched two steps ahead, and with
+            // it the lane's luma coefficient block and WHT coefficient one step ahead (registers).  prefetch(s) is what
+            // step s issues: the record of MB x+2 and, from the record of MB x+1 (fetched by the previous call), the
+            // coefficients of MB x+1.
             const uint4* mb_row = mb + size_t(fr.mb_base) + size_t(row_ok ? y : 0) * mbw;
-            uint4 rec_next = make_uint4(0, 0, 0, 0);
-            if (row_ok && g == 0) rec_next = mb_row[0];
-            settle(rec_next);
+            const int16_t* const cfr = coeff + size_t(fr.coeff_base) * 16;
+            uint4 rec_n1 = make_uint4(0, 0, 0, 0), rec_n2 = make_uint4(0, 0, 0, 0);     // records of MB x+1, x+2
+            uint4 nl0 = make_uint4(0, 0, 0, 0), nl1 = make_uint4(0, 0, 0, 0);           // luma block l of MB x+1
+            uint32_t nwv = 0;                                                           // WHT coefficient l of MB x+1
+            auto prefetch = [&](int s_) {
+                const int x_ = s_ - 2 * g;
+                rec_n1 = rec_n2;
+                if (row_ok && x_ + 2 >= 0 && x_ + 2 < mbw) rec_n2 = mb_row[x_ + 2];
+                nl0 = make_uint4(0, 0, 0, 0); nl1 = make_uint4(0, 0, 0, 0); nwv = 0;
+                if (row_ok && x_ + 1 >= 0 && x_ + 1 < mbw) {
+                    const uint32_t w2n = rec_n1.z;
+                    const int whtn = (w2n >> WP_MB_WHT_BIT) & 1;
+                    const int16_t* cbn = cfr + size_t(rec_n1.w) * 16;
+                    if ((w2n >> l) & 1) {
+                        const uint4* bp = reinterpret_cast<const uint4*>(cbn + size_t(whtn + __popc(w2n & ((1u << l) - 1u))) * 16);
+                        nl0 = bp[0]; nl1 = bp[1];
+                    }
+                    if (whtn) nwv = uint32_t(int(cbn[l]));
+                }
+            };
+            prefetch(-2);
+            prefetch(-1);
+            settle(rec_n1); settle(rec_n2); settle(nl0); settle(nl1); settle(nwv);
             uint32_t pending_publish = 0;
 
+            WP_PROF_MARK(9);
             for (int s = 0; s < n_steps; ++s) {
+                WP_PROF_MARK(8);
                 const int x = s - 2 * g;
                 const bool act = row_ok && x >= 0 && x < mbw;
-                const uint4 rec = act ? rec_next : make_uint4(0, 0, 0, 0);
-                if (row_ok && x + 1 >= 0 && x + 1 < mbw) rec_next = mb_row[x + 1];
+                const uint4 rec = act ? rec_n1 : make_uint4(0, 0, 0, 0);
+                const uint4 cl0 = nl0, cl1 = nl1;
+                const int wv_cur = int(nwv);
+                prefetch(s);
 
                 // ---- top context of group 0 comes from the band above, through the output tiles: issue the
                 //      loads now, park them in the LDS ring after the residuals have been computed ----
@@ -281,6 +320,7 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                     }
                 }
 
+                WP_PROF_MARK(0);
                 // ---- residuals (independent of the neighbours) ----
                 const uint32_t w2 = rec.z;
                 const bool i16 = (w2 >> WP_MB_I16_BIT) & 1;
@@ -293,10 +333,10 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
 #pragma unroll
                     for (int k = 0; k < 16; ++k) c[k] = 0;
                     const bool present = act && ((w2 >> l) & 1);
-                    if (present) load_block(cbase + size_t(has_wht + __popc(w2 & ((1u << l) - 1u))) * 16, c);
+                    if (present) unpack_block(cl0, cl1, c);
                     int dc16 = 0;
                     if (__builtin_amdgcn_ballot_w64(act && has_wht) != 0) {
-                        const int wv = (act && has_wht) ? int(cbase[l]) : 0;
+                        const int wv = (act && has_wht) ? wv_cur : 0;
                         dc16 = wht_dc_lanes(wv, l);
                         if (act && has_wht) c[0] = dc16; else dc16 = 0;
                     }
@@ -307,9 +347,11 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                 uint32_t cev[4] = {0, 0, 0, 0}, cod[4] = {0, 0, 0, 0};
                 if (act && chroma_lane && ((w2 >> cn) & 1)) {
                     int c[16];
-                    load_block(cbase + size_t(has_wht + __popc(w2 & ((1u << cn) - 1u))) * 16, c);
+                    const uint4* bp = reinterpret_cast<const uint4*>(cbase + size_t(has_wht + __popc(w2 & ((1u << cn) - 1u))) * 16);
+                    unpack_block(bp[0], bp[1], c);
                     idct_residual(c, cev, cod);
                 }
+                WP_PROF_MARK(1);
                 if (fetch_top) {
                     if (s == 0) lds.ring[0][0][l] = top_a;
                     if (s + 1 < mbw) lds.ring[0][(s + 1) & 3][l] = top_b;
@@ -336,7 +378,7 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                     } else {
                         const uint32_t* slot = lds.ring[g][x & 3];
                         if (l < 4) tile32(T.y[0], 4 + 4 * l) = slot[l];
-                        if (l == 4) tile32(T.y[0], 20) = x == mbw - 1 ? (slot[3] >> 24) * 0x01010101u : lds.ring[g][(x + 1) & 3][0];
+                        if (l == 4) tile32(T.y[0], 20) = x == mbw - 1 ? splat4(int(slot[3] >> 24)) : lds.ring[g][(x + 1) & 3][0];
                         if (l == 6 || l == 7) tile32(T.c[0], 4 + 4 * (l - 6)) = slot[4 + (l - 6)];
                         if (l == 8 || l == 9) tile32(T.c[0], 20 + 4 * (l - 8)) = slot[6 + (l - 8)];
                     }
@@ -344,6 +386,7 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                     if (l >= 1 && l <= 3) tile32(T.y[4 * l], 20) = tile32(T.y[0], 20);   // rows 4/8/12 keep the MB's top-right (:572-576)
                     __builtin_amdgcn_wave_barrier();
 
+                    WP_PROF_MARK(2);
                     // ---- luma ----
                     if (i16) {
                         int mode = int(rec.x & 15);
@@ -365,6 +408,7 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                         }
                     }
                 }
+                WP_PROF_MARK(3);
                 // i4: blocks in raster order predict from already reconstructed neighbours; block (bj,bi)
                 // is ready at mini-step bi + 2*bj (it needs (bj,bi-1), (bj-1,bi) and (bj-1,bi+1)).
                 if (__builtin_amdgcn_ballot_w64(act && !i16) != 0) {
@@ -388,6 +432,7 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                         __builtin_amdgcn_wave_barrier();
                     }
                 }
+                WP_PROF_MARK(4);
                 if (act) {
                     // ---- chroma: one 8x8 predictor per plane, four 4x4 residual blocks each ----
                     const int c8 = int((w2 >> WP_MB_C8_SHIFT) & 3);
@@ -417,7 +462,8 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                 // ---- tell the band below how far this band's last row has got.  The value published here is the
                 //      one of the PREVIOUS step: its stores were issued a whole step ago, so the release fence
                 //      (s_waitcnt vmcnt(0)) does not stall on store acknowledgements ----
-                settle(rec_next);        // the prefetch has had the whole step to land; wait for it before this step's stores go out
+                WP_PROF_MARK(5);
+                settle(rec_n2); settle(nl0); settle(nl1); settle(nwv);   // the prefetches have had the whole step to land; wait for them before this step's stores go out
                 if (has_below) {
                     if (pending_publish) publish_progress(&progress[wave], pending_publish);
                     const int done = s - 2 * (kBandRows - 1) + 1;
@@ -436,6 +482,7 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                     *reinterpret_cast<uint2*>(tile + kTileCb + 8 * l) = make_uint2(tile32(cr, cc), tile32(cr, cc + 4));
                 }
                 __builtin_amdgcn_wave_barrier();
+                WP_PROF_MARK(6);
                 // ---- hand the bottom row to the group below (same wavefront, two steps later) ----
                 if (act && g + 1 < kBandRows && l < 8) {
                     const uint32_t v = l < 4 ? tile32(T.y[16], 4 + 4 * l)
@@ -445,16 +492,30 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                 }
             }
             if (has_below && pending_publish) publish_progress(&progress[wave], pending_publish);
+            WP_PROF_MARK(7);
         }
         seq += uint32_t(n_bands);
     }
+    WP_PROF_FLUSH(0);
 }
 
+#ifdef WP_PROFILE
+__device__ unsigned long long wp_prof[32];
+#endif
 }  // namespace wpk
 
-extern "C" int wpk_launch_vp8_recon(int n, int grid, const wp_vp8_frame* d_frames, const void* d_mb, const int16_t* d_coeff,
+#ifdef WP_PROFILE
+extern "C" int wp_debug_profile(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(wpk::wp_prof), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(wpk::wp_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
+extern "C" int wpk_launch_vp8_recon(int n, int cus, const wp_vp8_frame* d_frames, const void* d_mb, const int16_t* d_coeff,
                                     uint8_t* d_rtiles, hipStream_t stream) {
-    hipLaunchKernelGGL(wpk::vp8_recon_kernel, dim3(grid), dim3(wpk::kWavesPerWG * wpk::kWave), 0, stream,
+    const int grid = n < cus * wpk::kReconWGsPerCU ? n : cus * wpk::kReconWGsPerCU;
+    hipLaunchKernelGGL(wpk::vp8_recon_kernel, dim3(grid), dim3(wpk::kReconWaves * wpk::kWave), 0, stream,
                        n, d_frames, reinterpret_cast<const uint4*>(d_mb), d_coeff, d_rtiles);
     return int(hipGetLastError());
 }
