@@ -21,9 +21,10 @@
 namespace wpk {
 
 struct alignas(16) FilterTile {
-    uint8_t y[24][32];          // rows 0..7: the 8 rows above, 8..23: MB rows; cols: MB slot (x & 1) * 16
+    uint8_t y[24][48];          // rows 0..7: the 8 rows above, 8..23: MB rows; cols: MB slot (x & 1) * 16; pitch 48 = 12 dwords:
+                                // the 16-byte row accesses (lane = row) of 8 consecutive lanes cover all 32 banks once
     uint8_t c[2][12][16];       // rows 0..3: above, 4..11: MB rows; cols: slot (x & 1) * 8
-    uint8_t pad[32];            // 1184 B = 296 dwords: the four groups' tiles start 8 banks apart
+    uint8_t pad[16];            // 1552 B = 388 dwords: the four groups' tiles start 4 banks apart
 };
 struct alignas(16) FilterWaveLds {
     FilterTile tile[kBandRows];

@@ -18,10 +18,11 @@
 
 namespace wpk {
 
-struct ReconTile {              // bytes; row pitch 32 so that 4-pixel groups are dword aligned
-    uint8_t y[17][32];          // row 0: [3] corner, [4..19] top, [20..23] top-right; rows 1..16: [3] left, [4..19] pixels
-    uint8_t c[9][32];           // Cb at cols 3 | 4..11, Cr at cols 19 | 20..27; row 0 is the top border
-    uint8_t pad[32];            // 864 B = 216 dwords: the four groups' tiles start 24 banks apart (no 2-way conflicts)
+struct ReconTile {              // bytes; row pitch 36 = 9 dwords: 4-pixel groups stay dword aligned, and both the column
+                                // accesses (lane = row) and the i4 block accesses (lane = block) hit 16 different banks
+    uint8_t y[17][36];          // row 0: [3] corner, [4..19] top, [20..23] top-right; rows 1..16: [3] left, [4..19] pixels
+    uint8_t c[9][36];           // Cb at cols 3 | 4..11, Cr at cols 19 | 20..27; row 0 is the top border
+    uint8_t pad[24];            // 960 B = 240 dwords: the four groups' tiles start 16 banks apart
 };
 struct ReconWaveLds {
     ReconTile tile[kBandRows];
@@ -210,12 +211,22 @@ __device__ __forceinline__ void pred_large(int mode, uint32_t top4, uint32_t lef
     }
 }
 
-// Sum over the 16 lanes of a group (row of 16 lanes in DPP terms).
+// Cross-lane sums with DPP (VALU modifiers, no LDS round trip).  A group of 16 lanes is one DPP row.
+template <int CTRL> __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+constexpr int kDppQuadXor1 = 0xB1, kDppQuadXor2 = 0x4E, kDppHalfMirror = 0x141, kDppRowRor = 0x120;
+// Sum over the 16 lanes of a group, result in every lane (rotations by 8, 4, 2, 1).
 __device__ __forceinline__ int group_sum16(int v) {
-    v += __shfl_xor(v, 1, 16);
-    v += __shfl_xor(v, 2, 16);
-    v += __shfl_xor(v, 4, 16);
-    v += __shfl_xor(v, 8, 16);
+    v += dpp<kDppRowRor + 8>(v);
+    v += dpp<kDppRowRor + 4>(v);
+    v += dpp<kDppRowRor + 2>(v);
+    v += dpp<kDppRowRor + 1>(v);
+    return v;
+}
+// Sum over each half (8 lanes) of a group, result in every lane of the half.
+__device__ __forceinline__ int group_sum8(int v) {
+    v += dpp<kDppQuadXor1>(v);
+    v += dpp<kDppQuadXor2>(v);
+    v += dpp<kDppHalfMirror>(v);        // lane i <-> 7 - i: the other quad of the half
     return v;
 }
 
@@ -439,9 +450,7 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                     const int plane = l >> 3;                 // lanes 0..7 sum Cb borders, 8..15 Cr borders
                     const int cb = plane ? 20 : 4;
                     int tsum = int(T.c[0][cb + (l & 7)]), lsum = int(T.c[1 + (l & 7)][cb - 1]);
-                    tsum += __shfl_xor(tsum, 1, 16); lsum += __shfl_xor(lsum, 1, 16);
-                    tsum += __shfl_xor(tsum, 2, 16); lsum += __shfl_xor(lsum, 2, 16);
-                    tsum += __shfl_xor(tsum, 4, 16); lsum += __shfl_xor(lsum, 4, 16);
+                    tsum = group_sum8(tsum); lsum = group_sum8(lsum);
                     int dcv = (tsum + lsum + 8) >> 4;
                     if (c8 == 0) {
                         if (x == 0) dcv = y == 0 ? 0x80 : (tsum + 4) >> 3;
