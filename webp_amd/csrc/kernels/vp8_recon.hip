@@ -285,11 +285,15 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
             uint4 rec_n1 = make_uint4(0, 0, 0, 0), rec_n2 = make_uint4(0, 0, 0, 0);     // records of MB x+1, x+2
             uint4 nl0 = make_uint4(0, 0, 0, 0), nl1 = make_uint4(0, 0, 0, 0);           // luma block l of MB x+1
             uint32_t nwv = 0;                                                           // WHT coefficient l of MB x+1
+            uint4 nc0 = make_uint4(0, 0, 0, 0), nc1 = make_uint4(0, 0, 0, 0);           // chroma block of MB x+1 (chroma lanes)
+            const int cn = 16 + (l & 3) + ((l & 8) ? 4 : 0);                            // lanes 0-3: Cb blocks, 8-11: Cr blocks
+            const bool chroma_lane = (l & 4) == 0;
             auto prefetch = [&](int s_) {
                 const int x_ = s_ - 2 * g;
                 rec_n1 = rec_n2;
                 if (row_ok && x_ + 2 >= 0 && x_ + 2 < mbw) rec_n2 = mb_row[x_ + 2];
                 nl0 = make_uint4(0, 0, 0, 0); nl1 = make_uint4(0, 0, 0, 0); nwv = 0;
+                nc0 = make_uint4(0, 0, 0, 0); nc1 = make_uint4(0, 0, 0, 0);
                 if (row_ok && x_ + 1 >= 0 && x_ + 1 < mbw) {
                     const uint32_t w2n = rec_n1.z;
                     const int whtn = (w2n >> WP_MB_WHT_BIT) & 1;
@@ -299,11 +303,15 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                         nl0 = bp[0]; nl1 = bp[1];
                     }
                     if (whtn) nwv = uint32_t(int(cbn[l]));
+                    if (chroma_lane && ((w2n >> cn) & 1)) {
+                        const uint4* bp = reinterpret_cast<const uint4*>(cbn + size_t(whtn + __popc(w2n & ((1u << cn) - 1u))) * 16);
+                        nc0 = bp[0]; nc1 = bp[1];
+                    }
                 }
             };
             prefetch(-2);
             prefetch(-1);
-            settle(rec_n1); settle(rec_n2); settle(nl0); settle(nl1); settle(nwv);
+            settle(rec_n1); settle(rec_n2); settle(nl0); settle(nl1); settle(nwv); settle(nc0); settle(nc1);
             uint32_t pending_publish = 0;
 
             WP_PROF_MARK(9);
@@ -312,7 +320,7 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                 const int x = s - 2 * g;
                 const bool act = row_ok && x >= 0 && x < mbw;
                 const uint4 rec = act ? rec_n1 : make_uint4(0, 0, 0, 0);
-                const uint4 cl0 = nl0, cl1 = nl1;
+                const uint4 cl0 = nl0, cl1 = nl1, cc0 = nc0, cc1 = nc1;
                 const int wv_cur = int(nwv);
                 prefetch(s);
 
@@ -336,7 +344,6 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                 const uint32_t w2 = rec.z;
                 const bool i16 = (w2 >> WP_MB_I16_BIT) & 1;
                 const int has_wht = (w2 >> WP_MB_WHT_BIT) & 1;
-                const int16_t* cbase = coeff + (size_t(fr.coeff_base) + rec.w) * 16;
 
                 uint32_t ev[4] = {0, 0, 0, 0}, od[4] = {0, 0, 0, 0};          // luma residual of block l
                 {
@@ -353,13 +360,10 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                     }
                     if (present || dc16 != 0) idct_residual(c, ev, od);
                 }
-                const bool chroma_lane = (l & 4) == 0;                         // lanes 0-3: Cb blocks, 8-11: Cr blocks
-                const int cn = 16 + (l & 3) + ((l & 8) ? 4 : 0);
                 uint32_t cev[4] = {0, 0, 0, 0}, cod[4] = {0, 0, 0, 0};
                 if (act && chroma_lane && ((w2 >> cn) & 1)) {
                     int c[16];
-                    const uint4* bp = reinterpret_cast<const uint4*>(cbase + size_t(has_wht + __popc(w2 & ((1u << cn) - 1u))) * 16);
-                    unpack_block(bp[0], bp[1], c);
+                    unpack_block(cc0, cc1, c);
                     idct_residual(c, cev, cod);
                 }
                 WP_PROF_MARK(1);
@@ -472,7 +476,7 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                 //      one of the PREVIOUS step: its stores were issued a whole step ago, so the release fence
                 //      (s_waitcnt vmcnt(0)) does not stall on store acknowledgements ----
                 WP_PROF_MARK(5);
-                settle(rec_n2); settle(nl0); settle(nl1); settle(nwv);   // the prefetches have had the whole step to land; wait for them before this step's stores go out
+                settle(rec_n2); settle(nl0); settle(nl1); settle(nwv); settle(nc0); settle(nc1);   // the prefetches have had the whole step to land; wait for them before this step's stores go out
                 if (has_below) {
                     if (pending_publish) publish_progress(&progress[wave], pending_publish);
                     const int done = s - 2 * (kBandRows - 1) + 1;
