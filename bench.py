@@ -122,8 +122,16 @@ def main():
     times = {"vp8_recon_kernel": t_recon, "vp8_filter_kernel": t_filter, "vp8_finish_kernel": t_conv}
     dom = max(times, key=times.get)
     achieved = alg[dom] / (times[dom] * 1e-3) / 1e9
+    # HBM traffic of that kernel from the PMC counters: measured by a separate rocprofv3 --pmc run of this same command
+    # (tools/pmc.sh + tools/pmc_traffic.list), committed under profiles/; scaled if --images differs from that run.
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        traffic = int(tj["kernels"][dom]["hbm_bytes"] * args.images / tj["images_per_launch"])
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(times[dom], 4),
                 "stages_ms": {k: round(v, 4) for k, v in times.items()},
                 "stages_GBs": {k: round(alg[k] / (times[k] * 1e-3) / 1e9, 2) for k in times},

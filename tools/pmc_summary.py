@@ -1,15 +1,20 @@
-"""Sums rocprofv3 --pmc counter_collection CSVs per kernel and counter."""
-import csv, glob, sys, collections
+"""Sums rocprofv3 --pmc counter_collection CSVs per kernel and counter; per-dispatch = total / dispatches that carry the counter."""
+import csv, glob, sys, collections, json
 root = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
-cnt = collections.defaultdict(set)
+ids = collections.defaultdict(lambda: collections.defaultdict(set))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].split("(")[0].replace("wpk::", "")
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        cnt[k].add(r["Dispatch_Id"])
+        ids[k][r["Counter_Name"]].add((f, r["Dispatch_Id"]))
+out = {}
 for k in acc:
-    n = max(1, len(cnt[k]) // max(1, len(glob.glob(root + "/p*/"))))
-    print("==", k, "dispatches/pass ~", n)
+    print("==", k)
+    out[k] = {}
     for c, v in sorted(acc[k].items()):
-        print("   %-28s total %.4g   per dispatch %.4g" % (c, v, v / n))
+        n = max(1, len(ids[k][c]))
+        out[k][c] = v / n
+        print("   %-28s total %.4g   dispatches %d   per dispatch %.4g" % (c, v, n, v / n))
+if len(sys.argv) > 2:
+    json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
