@@ -14,8 +14,18 @@ db.recon(planes=False); torch.cuda.synchronize()
 L.wp_debug_profile(buf, 1)
 db.recon(planes=False); torch.cuda.synchronize()
 L.wp_debug_profile(buf, 0)
+def show(names):
+    tot = sum(buf[i] for i in range(10))
+    for i, nm in enumerate(names):
+        print("%-18s %12d  %5.1f%%" % (nm, buf[i], 100.0 * buf[i] / max(tot, 1)))
+    print("total cycles", tot)
+
+
 names = ["0 wait+top loads", "1 residuals", "2 tile prep", "3 i16", "4 i4 loop", "5 chroma", "6 publish+store", "7 band end", "8 loop top", "9 band start"]
-tot = sum(buf[i] for i in range(10))
-for i, nm in enumerate(names):
-    print("%-18s %12d  %5.1f%%" % (nm, buf[i], 100.0 * buf[i] / max(tot, 1)))
-print("total cycles", tot)
+print("== recon"); show(names)
+db.loopfilter(planes=False); torch.cuda.synchronize()
+L.wp_debug_profile_filter(buf, 1)
+db.loopfilter(planes=False); torch.cuda.synchronize()
+L.wp_debug_profile_filter(buf, 0)
+print("== filter")
+show(["0 wait+prefetch", "1 tile fill", "2 V edges", "3 H edges", "4 publish", "5 emit+handdown", "6", "7", "8 loop top", "9 band start"])

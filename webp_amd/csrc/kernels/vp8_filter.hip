@@ -20,6 +20,10 @@
 
 namespace wpk {
 
+#ifdef WP_PROFILE
+static __device__ unsigned long long wp_prof[32];
+#endif
+
 struct alignas(16) FilterTile {
     uint8_t y[24][48];          // rows 0..7: the 8 rows above, 8..23: MB rows; cols: MB slot (x & 1) * 16; pitch 48 = 12 dwords:
                                 // the 16-byte row accesses (lane = row) of 8 consecutive lanes cover all 32 banks once
@@ -150,6 +154,7 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
     __syncthreads();
 
     uint32_t seq = 1;
+    WP_PROF_DECL;
     for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
         const wp_vp8_frame fr = frames[f];
         const int mbw = fr.mbw, mbh = fr.mbh;
@@ -196,7 +201,9 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
             settle(nx_y); settle(nx_ty); settle(nx_c); settle(nx_tc); settle(nx_fp);
             uint32_t pending_publish = 0;
 
+            WP_PROF_MARK(9);
             for (int s = 0; s < n_steps; ++s) {
+                WP_PROF_MARK(8);
                 const int x = s - 2 * g;
                 const bool act = row_ok && x >= 0 && x < mbw;
                 const uint4 cur_y = nx_y;
@@ -212,6 +219,7 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
                     if (top_lane) { nx_ty = *reinterpret_cast<const uint2*>(trow_y + o); nx_tc = *reinterpret_cast<const uint32_t*>(trow_c + o); }
                 }
 
+                WP_PROF_MARK(0);
                 const int level = int(fp & 0xff), ilevel = int((fp >> 8) & 0xff), hlevel = int((fp >> 16) & 0xff);
                 const bool inner = (fp >> 24) & 1;
                 const bool do_filter = act && level != 0;                   // `if (f.level == 0) continue` (:421, :449)
@@ -233,6 +241,7 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
                 }
                 __builtin_amdgcn_wave_barrier();
 
+                WP_PROF_MARK(1);
                 if (do_filter) {
                     // ---- 2a. vertical edges: lane = pixel row; columns -4..15 relative to the MB ----
                     {
@@ -255,6 +264,7 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+                WP_PROF_MARK(2);
                 if (do_filter) {
                     // ---- 2b. horizontal edges: lane = pixel column; rows -4..15 relative to the MB ----
                     {
@@ -276,6 +286,7 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
                 }
                 __builtin_amdgcn_wave_barrier();
 
+                WP_PROF_MARK(3);
                 // ---- tell the band below how far this band's last row has got: the value of the PREVIOUS step,
                 //      whose stores were issued a whole step ago (the release fence then does not wait for acks) ----
                 settle(nx_y); settle(nx_ty); settle(nx_c); settle(nx_tc); settle(nx_fp);   // prefetch landed long ago; wait before the stores go out
@@ -285,6 +296,7 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
                     pending_publish = done >= 1 ? ((q << kSeqShift) | uint32_t(done)) : 0u;
                 }
 
+                WP_PROF_MARK(4);
                 if (act) {
                     // ---- 3. emit S tile (x, y): rows -8..7, cols -8..7 relative to the MB, all final ----
                     uint8_t* st = srow + size_t(x) * kTileBytes;
@@ -316,14 +328,24 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+                WP_PROF_MARK(5);
             }
             if (has_below && pending_publish) publish_progress(&progress[wave], pending_publish);
         }
         seq += uint32_t(n_bands);
     }
+    WP_PROF_FLUSH(0);
 }
 
 }  // namespace wpk
+
+#ifdef WP_PROFILE
+extern "C" int wp_debug_profile_filter(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(wpk::wp_prof), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(wpk::wp_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 extern "C" int wpk_launch_vp8_filter(int n, int cus, const wp_vp8_frame* d_frames, const uint32_t* d_filt,
                                      const uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream) {

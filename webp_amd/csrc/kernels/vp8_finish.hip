@@ -10,8 +10,19 @@
 #include "wp_device.h"
 #include "wp_convert.h"
 
+// Everything this pass touches is used exactly once: non-temporal accesses keep it from displacing the tiles that the
+// wavefront kernels of the next launch re-read through L2.
+#ifdef WP_FINISH_NO_NT
+#define WP_NT_LOAD(p) (*(p))
+#define WP_NT_STORE(p, v) (*(p) = (v))
+#else
+#define WP_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define WP_NT_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#endif
+
 namespace wpk {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kFinishCols = 256;                       // output luma columns per workgroup
 constexpr int kFinishTiles = kFinishCols / 16 + 1;      // source tiles that can overlap them
 
@@ -31,7 +42,7 @@ void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* _
     const uint8_t* src = (shifted ? Sp + size_t(fr.stile_base) * kTileBytes : Rp + size_t(fr.mb_base) * kTileBytes)
                        + (size_t(ty) * ntx + tx0) * kTileBytes;
     const int t = threadIdx.x;
-    for (int i = t; i < nt * (kTileBytes / 16); i += 256) tiles4[i] = reinterpret_cast<const uint4*>(src)[i];
+    for (int i = t; i < nt * (kTileBytes / 16); i += 256) { const u32x4 v = WP_NT_LOAD(reinterpret_cast<const u32x4*>(src) + i); tiles4[i] = make_uint4(v.x, v.y, v.z, v.w); }
     __syncthreads();
     const uint32_t* tiles32 = reinterpret_cast<const uint32_t*>(tiles4);
     const uint16_t* tiles16 = reinterpret_cast<const uint16_t*>(tiles4);
@@ -51,7 +62,7 @@ void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* _
             const int py = 16 * ty - shift + r;
             if (py < 0 || py >= 16 * mbh) continue;
             const uint32_t y4 = tiles32[k * (kTileBytes / 4) + 4 * r + (c4 >> 2)];
-            if (Y) *reinterpret_cast<uint32_t*>(Y + size_t(py) * ystride + px) = y4;
+            if (Y) WP_NT_STORE(reinterpret_cast<uint32_t*>(Y + size_t(py) * ystride + px), y4);
             if (dst && py < height && px < width) {
                 const int ci = k * (kTileBytes / 2) + 4 * (r >> 1) + (c4 >> 2);       // 16-bit index of the two chroma samples
                 const uint32_t u2 = tiles16[ci + kTileCb / 2], v2 = tiles16[ci + kTileCr / 2];
@@ -65,7 +76,7 @@ void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* _
                 const uint4 o = convert_px4(y4, u2, v2, a4);
                 uint8_t* p = dst + pix * 4;
                 if (npx == 4 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-                    *reinterpret_cast<uint4*>(p) = o;
+                    { const u32x4 ov4 = {o.x, o.y, o.z, o.w}; WP_NT_STORE(reinterpret_cast<u32x4*>(p), ov4); }
                 } else {
                     const uint32_t ov[4] = {o.x, o.y, o.z, o.w};
                     for (int j = 0; j < npx; ++j) reinterpret_cast<uint32_t*>(p)[j] = ov[j];
@@ -83,7 +94,7 @@ void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* _
             const int kk = (4 * dw + (shift >> 1)) >> 3, half = ((4 * dw + (shift >> 1)) >> 2) & 1;
             if (kk < nt && cy >= 0 && cy < 8 * mbh && cx < cstride) {
                 uint8_t* P = plane ? Vp + fr.v_off : Up + fr.u_off;
-                *reinterpret_cast<uint32_t*>(P + size_t(cy) * cstride + cx) = tiles32[kk * (kTileBytes / 4) + (kTileCb / 4) + 16 * plane + 2 * row + half];
+                WP_NT_STORE(reinterpret_cast<uint32_t*>(P + size_t(cy) * cstride + cx), tiles32[kk * (kTileBytes / 4) + (kTileCb / 4) + 16 * plane + 2 * row + half]);
             }
         }
     }

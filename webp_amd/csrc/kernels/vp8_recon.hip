@@ -18,6 +18,10 @@
 
 namespace wpk {
 
+#ifdef WP_PROFILE
+static __device__ unsigned long long wp_prof[32];
+#endif
+
 struct ReconTile {              // bytes; row pitch 36 = 9 dwords: 4-pixel groups stay dword aligned, and both the column
                                 // accesses (lane = row) and the i4 block accesses (lane = block) hit 16 different banks
     uint8_t y[17][36];          // row 0: [3] corner, [4..19] top, [20..23] top-right; rows 1..16: [3] left, [4..19] pixels
@@ -512,9 +516,6 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
     WP_PROF_FLUSH(0);
 }
 
-#ifdef WP_PROFILE
-__device__ unsigned long long wp_prof[32];
-#endif
 }  // namespace wpk
 
 #ifdef WP_PROFILE
