@@ -193,8 +193,8 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
             uint32_t nx_fp = 0, nx_tc = 0;
             if (has_above) wait_progress(&progress[prev_wave], ((q - 1) << kSeqShift) | uint32_t(min(2, mbw)));
             if (row_ok && g == 0) {
-                nx_y = *reinterpret_cast<const uint4*>(rrow + 16 * l);
-                nx_c = *reinterpret_cast<const uint2*>(rrow + kTileCb + 8 * l);
+                nx_y = ld_nt(reinterpret_cast<const uint4*>(rrow + 16 * l));
+                nx_c = ld_nt(reinterpret_cast<const uint2*>(rrow + kTileCb + 8 * l));
                 nx_fp = frow[0];
                 if (top_lane) { nx_ty = *reinterpret_cast<const uint2*>(trow_y); nx_tc = *reinterpret_cast<const uint32_t*>(trow_c); }
             }
@@ -213,8 +213,8 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
                     wait_progress(&progress[prev_wave], ((q - 1) << kSeqShift) | uint32_t(min(s + 3, mbw)));
                 if (row_ok && x + 1 >= 0 && x + 1 < mbw) {
                     const size_t o = size_t(x + 1) * kTileBytes;
-                    nx_y = *reinterpret_cast<const uint4*>(rrow + o + 16 * l);
-                    nx_c = *reinterpret_cast<const uint2*>(rrow + o + kTileCb + 8 * l);
+                    nx_y = ld_nt(reinterpret_cast<const uint4*>(rrow + o + 16 * l));
+                    nx_c = ld_nt(reinterpret_cast<const uint2*>(rrow + o + kTileCb + 8 * l));
                     nx_fp = frow[x + 1];
                     if (top_lane) { nx_ty = *reinterpret_cast<const uint2*>(trow_y + o); nx_tc = *reinterpret_cast<const uint32_t*>(trow_c + o); }
                 }
@@ -301,8 +301,8 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
                     // ---- 3. emit S tile (x, y): rows -8..7, cols -8..7 relative to the MB, all final ----
                     uint8_t* st = srow + size_t(x) * kTileBytes;
                     const uint2 a = t64(&T.y[l][pb + 8]), b = t64(&T.y[l][cb]);
-                    *reinterpret_cast<uint4*>(st + 16 * l) = make_uint4(a.x, a.y, b.x, b.y);
-                    *reinterpret_cast<uint2*>(st + kTileCb + 8 * l) = make_uint2(t32(&T.c[lp][lr][pb8 + 4]), t32(&T.c[lp][lr][cb8]));
+                    st_nt(reinterpret_cast<uint4*>(st + 16 * l), make_uint4(a.x, a.y, b.x, b.y));
+                    st_nt(reinterpret_cast<uint2*>(st + kTileCb + 8 * l), make_uint2(t32(&T.c[lp][lr][pb8 + 4]), t32(&T.c[lp][lr][cb8])));
                     if (x == mbw - 1) {        // right-most tile column: cols 8..15 (left half of tile mbw)
                         *reinterpret_cast<uint2*>(st + kTileBytes + 16 * l) = t64(&T.y[l][cb + 8]);
                         *reinterpret_cast<uint32_t*>(st + kTileBytes + kTileCb + 8 * l) = t32(&T.c[lp][lr][cb8 + 4]);

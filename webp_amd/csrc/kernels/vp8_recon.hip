@@ -304,12 +304,12 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                     const int16_t* cbn = cfr + size_t(rec_n1.w) * 16;
                     if ((w2n >> l) & 1) {
                         const uint4* bp = reinterpret_cast<const uint4*>(cbn + size_t(whtn + __popc(w2n & ((1u << l) - 1u))) * 16);
-                        nl0 = bp[0]; nl1 = bp[1];
+                        nl0 = ld_nt(bp); nl1 = ld_nt(bp + 1);
                     }
                     if (whtn) nwv = uint32_t(int(cbn[l]));
                     if (chroma_lane && ((w2n >> cn) & 1)) {
                         const uint4* bp = reinterpret_cast<const uint4*>(cbn + size_t(whtn + __popc(w2n & ((1u << cn) - 1u))) * 16);
-                        nc0 = bp[0]; nc1 = bp[1];
+                        nc0 = ld_nt(bp); nc1 = ld_nt(bp + 1);
                     }
                 }
             };
@@ -492,11 +492,11 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
                     //      luma row l and one chroma row, so the group emits the 384-byte tile as three full lines ----
                     uint8_t* tile = R + (size_t(y) * mbw + x) * kTileBytes;
                     const uint8_t* yr = T.y[1 + l];
-                    *reinterpret_cast<uint4*>(tile + 16 * l) = make_uint4(tile32(const_cast<uint8_t*>(yr), 4), tile32(const_cast<uint8_t*>(yr), 8),
-                                                                          tile32(const_cast<uint8_t*>(yr), 12), tile32(const_cast<uint8_t*>(yr), 16));
+                    st_nt(reinterpret_cast<uint4*>(tile + 16 * l), make_uint4(tile32(const_cast<uint8_t*>(yr), 4), tile32(const_cast<uint8_t*>(yr), 8),
+                                                                          tile32(const_cast<uint8_t*>(yr), 12), tile32(const_cast<uint8_t*>(yr), 16)));
                     uint8_t* cr = T.c[1 + (l & 7)];
                     const int cc = (l >> 3) ? 20 : 4;
-                    *reinterpret_cast<uint2*>(tile + kTileCb + 8 * l) = make_uint2(tile32(cr, cc), tile32(cr, cc + 4));
+                    st_nt(reinterpret_cast<uint2*>(tile + kTileCb + 8 * l), make_uint2(tile32(cr, cc), tile32(cr, cc + 4)));
                 }
                 __builtin_amdgcn_wave_barrier();
                 WP_PROF_MARK(6);

@@ -47,6 +47,21 @@ __device__ __forceinline__ void settle(uint32_t& v) { asm volatile("" : "+v"(v))
 __device__ __forceinline__ void settle(uint4& v) { settle(v.x); settle(v.y); settle(v.z); settle(v.w); }
 __device__ __forceinline__ void settle(uint2& v) { settle(v.x); settle(v.y); }
 
+// Non-temporal (streaming) global accesses for data that is used exactly once.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+#ifdef WP_NO_NT
+__device__ __forceinline__ uint4 ld_nt(const uint4* p) { return *p; }
+__device__ __forceinline__ uint2 ld_nt(const uint2* p) { return *p; }
+__device__ __forceinline__ void st_nt(uint4* p, uint4 v) { *p = v; }
+__device__ __forceinline__ void st_nt(uint2* p, uint2 v) { *p = v; }
+#else
+__device__ __forceinline__ uint4 ld_nt(const uint4* p) { const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint2 ld_nt(const uint2* p) { const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p)); return make_uint2(v.x, v.y); }
+__device__ __forceinline__ void st_nt(uint4* p, uint4 v) { const u32x4_t w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t*>(p)); }
+__device__ __forceinline__ void st_nt(uint2* p, uint2 v) { const u32x2_t w = {v.x, v.y}; __builtin_nontemporal_store(w, reinterpret_cast<u32x2_t*>(p)); }
+#endif
+
 // Optional per-phase cycle profile of the wavefront kernels (tuning builds only: -DWP_PROFILE).  Wave 0 of workgroup 0
 // accumulates s_memtime deltas per phase and adds them to wp_prof[] at the end of each band; tools read the symbol.
 #ifdef WP_PROFILE
