@@ -41,7 +41,14 @@ __device__ __forceinline__ uint4& t128(uint8_t* p) { return *reinterpret_cast<ui
 __device__ __forceinline__ void unpack4(uint32_t w, int* v) { v[0] = w & 0xff; v[1] = (w >> 8) & 0xff; v[2] = (w >> 16) & 0xff; v[3] = w >> 24; }
 __device__ __forceinline__ uint32_t pack4i(const int* v) { return uint32_t(v[0]) | uint32_t(v[1]) << 8 | uint32_t(v[2]) << 16 | uint32_t(v[3]) << 24; }
 __device__ __forceinline__ uint32_t& t32(uint8_t* p) { return *reinterpret_cast<uint32_t*>(p); }
-__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+// |a - b| for non-negative a, b in ONE instruction (v_sad_u32 with a zero accumulator) instead of sub, sub, max:
+// both kernels are bound by VALU issue, and most integer VALU instructions cost 4 cycles per wavefront
+// (tools/ubench/valu_rate.hip), so instruction count is what matters.
+__device__ __forceinline__ int absdiff(int a, int b) {
+    int d;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ int clamp127(int v) { return clampi(v, -127, 127); }   // Filter.hx:16-18 (symmetric)
 __device__ __forceinline__ int clamp15(int v) { return clampi(v, -15, 15); }      // Filter.hx:20-22
 __device__ __forceinline__ int clamp255(int v) { return clampi(v, 0, 255); }
@@ -53,7 +60,7 @@ __device__ __forceinline__ int clamp255(int v) { return clampi(v, 0, 255); }
 
 // filter2, one position (Filter.hx:29-50): returns the deltas for p0 (added) and q0 (subtracted)
 __device__ __forceinline__ void simple_edge(int p1, int& p0, int& q0, int q1, int level) {
-    const bool on = (iabs(p0 - q0) << 1) + (iabs(p1 - q1) >> 1) <= level;
+    const bool on = (absdiff(p0, q0) << 1) + (absdiff(p1, q1) >> 1) <= level;
     const int a = 3 * (q0 - p0) + clamp127(p1 - q1);
     const int a1 = on ? clamp15((a + 4) >> 3) : 0;
     const int a2 = on ? clamp15((a + 3) >> 3) : 0;
@@ -65,9 +72,9 @@ __device__ __forceinline__ void simple_edge(int p1, int& p0, int& q0, int q1, in
 template <bool FOUR>
 __device__ __forceinline__ void normal_edge(int p3, int& p2, int& p1, int& p0, int& q0, int& q1, int& q2, int q3,
                                             int level, int ilevel, int hlevel) {
-    const int d10 = iabs(p1 - p0), e10 = iabs(q1 - q0);
-    const int worst = max(max(max(iabs(p3 - p2), iabs(p2 - p1)), max(d10, e10)), max(iabs(q2 - q1), iabs(q3 - q2)));
-    const bool on = (iabs(p0 - q0) << 1) + (iabs(p1 - q1) >> 1) <= level && worst <= ilevel;
+    const int d10 = absdiff(p1, p0), e10 = absdiff(q1, q0);
+    const int worst = max(max(max(absdiff(p3, p2), absdiff(p2, p1)), max(d10, e10)), max(absdiff(q2, q1), absdiff(q3, q2)));
+    const bool on = (absdiff(p0, q0) << 1) + (absdiff(p1, q1) >> 1) <= level && worst <= ilevel;
     const bool hev = d10 > hlevel || e10 > hlevel;
     const int base = 3 * (q0 - p0);
     const int outer = clamp127(p1 - q1);
