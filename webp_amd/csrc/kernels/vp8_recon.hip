@@ -53,8 +53,8 @@ __device__ __forceinline__ short2_t as_s2(uint32_t v) { return __builtin_bit_cas
 
 // Residual of one 4x4 block: inverseDCT4 without the "+ prediction, clip8" tail
 // (Vp8Decoder.hx:905-935).  Row j comes back as two packed int16 pairs:
-// even[j] = (r[j][0], r[j][2]), odd[j] = (r[j][1], r[j][3]), each clamped to [-255, 255]
-// (clip8(pred + r) cannot tell larger magnitudes apart, pred being in 0..255).
+// even[j] = (r[j][0], r[j][2]), odd[j] = (r[j][1], r[j][3]), each saturated to int16 (clip8(pred + r), computed with a
+// saturating add, cannot tell larger magnitudes apart, pred being in 0..255).
 __device__ __forceinline__ void idct_residual(const int (&c)[16], uint32_t (&even)[4], uint32_t (&odd)[4]) {
     const int c1 = 85627, c2 = 35468;
     int m[4][4];
@@ -73,21 +73,20 @@ __device__ __forceinline__ void idct_residual(const int (&c)[16], uint32_t (&eve
         const int b = dc - m[2][j];
         const int cc = mul16(m[1][j], c2) - mul16(m[3][j], c1);
         const int d = mul16(m[1][j], c1) + mul16(m[3][j], c2);
-        const int r0 = clampi((a + d) >> 3, -255, 255), r1 = clampi((b + cc) >> 3, -255, 255);
-        const int r2 = clampi((b - cc) >> 3, -255, 255), r3 = clampi((a - d) >> 3, -255, 255);
-        even[j] = (uint32_t(r0) & 0xffff) | (uint32_t(r2) << 16);
-        odd[j] = (uint32_t(r1) & 0xffff) | (uint32_t(r3) << 16);
+        // v_cvt_pk_i16_i32 saturates to int16 and packs in one instruction
+        even[j] = as_u32(__builtin_amdgcn_cvt_pk_i16((a + d) >> 3, (b - cc) >> 3));
+        odd[j] = as_u32(__builtin_amdgcn_cvt_pk_i16((b + cc) >> 3, (a - d) >> 3));
     }
 }
 
 // clip8(pred + residual) for one row of four pixels (Vp8Decoder.hx:930-933, 991-996).
 __device__ __forceinline__ uint32_t add_clip_row(uint32_t pred, uint32_t even, uint32_t odd) {
-    const short2_t zero = {0, 0}, top = {255, 255};
-    short2_t lo = as_s2(pred & 0x00ff00ffu) + as_s2(even);
-    short2_t hi = as_s2((pred >> 8) & 0x00ff00ffu) + as_s2(odd);
-    lo = __builtin_elementwise_min(__builtin_elementwise_max(lo, zero), top);
-    hi = __builtin_elementwise_min(__builtin_elementwise_max(hi, zero), top);
-    return as_u32(lo) | (as_u32(hi) << 8);
+    const short2_t lo = __builtin_elementwise_add_sat(as_s2(pred & 0x00ff00ffu), as_s2(even));         // pixels 0, 2
+    const short2_t hi = __builtin_elementwise_add_sat(as_s2((pred >> 8) & 0x00ff00ffu), as_s2(odd));   // pixels 1, 3
+    uint32_t l8, h8;                                   // v_sat_pk_u8_i16: two int16 -> two bytes (low half), clamped to 0..255
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(l8) : "v"(as_u32(lo)));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(h8) : "v"(as_u32(hi)));
+    return __builtin_amdgcn_perm(h8, l8, 0x05010400u);   // bytes: l8[0], h8[0], l8[1], h8[1]
 }
 
 // Unpacks a stored coefficient block (16 x int16, natural order; two 16-byte halves) into ints.
