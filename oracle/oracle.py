@@ -84,6 +84,17 @@ def yuv420_to_argb(y, ystride, u, v, uvstride, a, width, height):
     lib().wo_yuv420_to_argb(_p(y), ystride, _p(u), _p(v), uvstride, _p(a), width, height, _p(out))
     return out
 
+def vp8_from_packed(mbw, mbh, mb, coeff, filt, filter_type):
+    """Reconstruction + loop filter from the packed buffers of include/webp_amd.h -> dict of filtered and unfiltered planes."""
+    n = mbw * mbh
+    out = {k: np.zeros(256 * n if k[0] == "y" else 64 * n, np.uint8) for k in ("y", "u", "v", "y0", "u0", "v0")}
+    mb = np.ascontiguousarray(mb, np.uint32); coeff = np.ascontiguousarray(coeff, np.int16); filt = np.ascontiguousarray(filt, np.uint32)
+    rc = lib().wo_vp8_from_packed(mbw, mbh, _p(mb), _p(coeff), _p(filt), filter_type,
+                                  _p(out["y"]), _p(out["u"]), _p(out["v"]), _p(out["y0"]), _p(out["u0"]), _p(out["v0"]))
+    assert rc == 0
+    return out
+
+
 def inverse_predictor(old_width, bits, tpix, pix, h):
     pix = pix.copy(); lib().wo_inverse_predictor(old_width, bits, _p(tpix), _p(pix), h); return pix
 def inverse_cross_color(old_width, bits, tpix, pix, h):

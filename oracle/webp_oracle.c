@@ -901,6 +901,59 @@ static int vp8_decodeFrame(Vp8* d, int keep_unfiltered) {
     return WO_OK;
 }
 
+/* Test hook: the pixel half of Vp8Decoder.decodeFrame driven from the PACKED buffers of include/webp_amd.h (MB records,
+ * sparse coefficient blocks, filter records) instead of the bitstream, so that reconstruction and loop filter can be
+ * checked on inputs no encoder produces (full-range coefficients, every mode at every position, arbitrary filter
+ * records).  Follows reconstruct() :785-821 per MB in raster order, then simpleFilter / normalFilter.  Absent blocks are
+ * zero; every block goes through the full inverseDCT4 (bit-identical to the DC-only / skipped paths).
+ * y0/u0/v0 (optional) receive the unfiltered planes. */
+int wo_vp8_from_packed(int mbw, int mbh, const uint32_t* mb, const int16_t* coeff, const uint32_t* filt, int filter_type,
+                       uint8_t* y, uint8_t* u, uint8_t* v, uint8_t* y0, uint8_t* u0, uint8_t* v0) {
+    Vp8* d = (Vp8*)calloc(1, sizeof(Vp8));
+    if (!d) return fail(WO_ERR_ALLOC, "alloc");
+    d->mbw = mbw; d->mbh = mbh;
+    d->YStride = 16 * mbw; d->CStride = 8 * mbw;
+    d->Y = y; d->Cb = u; d->Cr = v;
+    const int nmb = mbw * mbh;
+    FilterParam* fps = (FilterParam*)calloc(nmb ? nmb : 1, sizeof(FilterParam));
+    d->perMB = (FilterParam**)calloc(nmb ? nmb : 1, sizeof(FilterParam*));
+    if (!fps || !d->perMB) { free(fps); free(d->perMB); free(d); return fail(WO_ERR_ALLOC, "alloc"); }
+    for (int mby = 0; mby < mbh; mby++) for (int mbx = 0; mbx < mbw; mbx++) {
+        const int idx = mby * mbw + mbx;
+        const uint32_t* w = mb + 4 * idx;
+        const int has_wht = (w[2] >> 24) & 1;
+        memset(d->coeff, 0, sizeof d->coeff);
+        vp8_prepareYBR(d, mbx, mby);
+        d->usePredY16 = (w[2] >> 25) & 1;
+        d->predC8 = (w[2] >> 26) & 3;
+        if (d->usePredY16) d->predY16 = w[0] & 15;
+        else for (int n = 0; n < 16; n++) d->predY4[n >> 2][n & 3] = (w[n >> 3] >> (4 * (n & 7))) & 15;
+        const int16_t* blk = coeff + (size_t)w[3] * 16;
+        if (has_wht) { for (int k = 0; k < 16; k++) d->coeff[whtCoeffBase + k] = blk[k]; blk += 16; }
+        for (int n = 0; n < 24; n++)
+            if ((w[2] >> n) & 1) { for (int k = 0; k < 16; k++) d->coeff[16 * n + k] = blk[k]; blk += 16; }
+        if (has_wht) vp8_inverseWHT16(d);
+        d->nzACMask = 0xffffff; d->nzDCMask = 0;
+        vp8_reconstructMacroblock(d, mbx, mby);
+        for (int yy = 0; yy < 16; yy++)
+            for (int k = 0; k < 16; k++) d->Y[(size_t)(16 * mby + yy) * d->YStride + 16 * mbx + k] = (uint8_t)d->ybr[ybrYY + yy][ybrYX + k];
+        for (int yy = 0; yy < 8; yy++)
+            for (int k = 0; k < 8; k++) {
+                d->Cb[(size_t)(8 * mby + yy) * d->CStride + 8 * mbx + k] = (uint8_t)d->ybr[ybrBY + yy][ybrBX + k];
+                d->Cr[(size_t)(8 * mby + yy) * d->CStride + 8 * mbx + k] = (uint8_t)d->ybr[ybrRY + yy][ybrRX + k];
+            }
+        fps[idx].level = filt[idx] & 0xff; fps[idx].ilevel = (filt[idx] >> 8) & 0xff;
+        fps[idx].hlevel = (filt[idx] >> 16) & 0xff; fps[idx].inner = (filt[idx] >> 24) & 1;
+        d->perMB[idx] = &fps[idx];
+    }
+    if (y0) memcpy(y0, y, (size_t)256 * nmb);
+    if (u0) memcpy(u0, u, (size_t)64 * nmb);
+    if (v0) memcpy(v0, v, (size_t)64 * nmb);
+    if (filter_type == 1) vp8_simpleFilter(d); else if (filter_type == 2) vp8_normalFilter(d);
+    free(fps); free(d->perMB); free(d);
+    return WO_OK;
+}
+
 static void vp8_init(Vp8* d, const uint8_t* data, int len) {   /* Vp8Decoder.hx:88-124 */
     memset(d, 0, sizeof *d);
     d->data = data; d->len = len; d->pos = 0;
