@@ -79,16 +79,6 @@ __device__ __forceinline__ void idct_residual(const int (&c)[16], uint32_t (&eve
     }
 }
 
-// clip8(pred + residual) for one row of four pixels (Vp8Decoder.hx:930-933, 991-996).
-__device__ __forceinline__ uint32_t add_clip_row(uint32_t pred, uint32_t even, uint32_t odd) {
-    const short2_t lo = __builtin_elementwise_add_sat(as_s2(pred & 0x00ff00ffu), as_s2(even));         // pixels 0, 2
-    const short2_t hi = __builtin_elementwise_add_sat(as_s2((pred >> 8) & 0x00ff00ffu), as_s2(odd));   // pixels 1, 3
-    uint32_t l8, h8;                                   // v_sat_pk_u8_i16: two int16 -> two bytes (low half), clamped to 0..255
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(l8) : "v"(as_u32(lo)));
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(h8) : "v"(as_u32(hi)));
-    return __builtin_amdgcn_perm(h8, l8, 0x05010400u);   // bytes: l8[0], h8[0], l8[1], h8[1]
-}
-
 // Unpacks a stored coefficient block (16 x int16, natural order; two 16-byte halves) into ints.
 __device__ __forceinline__ void unpack_block(const uint4& a, const uint4& b, int (&c)[16]) {
     const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -110,86 +100,131 @@ __device__ __forceinline__ int wht_dc_lanes(int v, int l) {
     return o >> 3;
 }
 
-// The ten 4x4 luma predictors (PredFunc.hx:118-418).  top8 = the 8 pixels above (4 above the
-// block + 4 above-right), left4 = the 4 pixels to the left (byte r = row r), corner = above-left.
+// ---- packed-byte helpers for the predictors: four pixels per dword, one instruction per four averages ----
+// v_lerp_u8: per byte (a + b + (c & 1)) >> 1.  avg2(a, b) = (a + b + 1) >> 1 is the rounding-up form, and
+// avg3(a, b, c) = (a + 2b + c + 2) >> 2 == up(down(a, c), b):  with a + c = 2m + r (r = 0 or 1) the left side is
+// floor((m + b + 1) / 2 + r / 4), and r / 4 never carries past the half-integer grid of (m + b + 1) / 2.
+__device__ __forceinline__ uint32_t avg2p(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }
+__device__ __forceinline__ uint32_t avg3p(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(a, c, 0u), b, 0x01010101u);
+}
+// bytes n..n+3 of the 8-byte value {hi, lo}
+#define WP_ALB(hi, lo, n) __builtin_amdgcn_alignbyte((hi), (lo), (n))
+// byte selector: selector bytes 0..3 pick from `lo`, 4..7 from `hi`
+#define WP_PERM(hi, lo, sel) __builtin_amdgcn_perm((hi), (lo), (sel))
+
+// clamp two int16 pairs (pixels 0,2 and pixels 1,3) to 0..255 and interleave them into four bytes
+__device__ __forceinline__ uint32_t clip_pack(short2_t p02, short2_t p13) {
+    uint32_t l8, h8;                                   // v_sat_pk_u8_i16: two int16 -> two bytes (low half), clamped to 0..255
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(l8) : "v"(as_u32(p02)));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(h8) : "v"(as_u32(p13)));
+    return WP_PERM(h8, l8, 0x05010400u);               // bytes: l8[0], h8[0], l8[1], h8[1]
+}
+
+// clip8(pred + residual) for one row of four pixels (Vp8Decoder.hx:930-933, 991-996).
+__device__ __forceinline__ uint32_t add_clip_row(uint32_t pred, uint32_t even, uint32_t odd) {
+    return clip_pack(__builtin_elementwise_add_sat(as_s2(pred & 0x00ff00ffu), as_s2(even)),          // pixels 0, 2
+                     __builtin_elementwise_add_sat(as_s2((pred >> 8) & 0x00ff00ffu), as_s2(odd)));   // pixels 1, 3
+}
+
+// TrueMotion (PredFunc.hx TM variants): row r = clip(top + left[r] - corner), in packed 16-bit arithmetic
+__device__ __forceinline__ void pred_tm(uint32_t top4, uint32_t left4, int corner, uint32_t (&row)[4]) {
+    const short2_t c2 = as_s2(uint32_t(corner) * 0x00010001u);
+    const short2_t t02 = as_s2(top4 & 0x00ff00ffu) - c2, t13 = as_s2((top4 >> 8) & 0x00ff00ffu) - c2;
+    const uint32_t sel[4] = {0x0c000c00u, 0x0c010c01u, 0x0c020c02u, 0x0c030c03u};      // (left[r], 0, left[r], 0)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const short2_t lr = as_s2(WP_PERM(0u, left4, sel[r]));
+        row[r] = clip_pack(t02 + lr, t13 + lr);
+    }
+}
+
+// The ten 4x4 luma predictors (PredFunc.hx:118-418).  top_lo / top_hi = the 8 pixels above (4 above the block + 4
+// above-right), left4 = the 4 pixels to the left (byte r = row r), corner = above-left.  The directional modes read
+// a window of the edge vector X = [L3 L2 L1 L0 | C T0 T1 T2 | T3 T4 T5 T6 | T7 ...] through the 3-tap (A3[i], centred
+// on X[i]) and 2-tap (A2[i] = avg2(X[i], X[i+1])) averages; with four pixels per dword every row is a byte window.
 __device__ __forceinline__ void pred4x4(int mode, uint32_t top_lo, uint32_t top_hi, uint32_t left4, int corner, uint32_t (&row)[4]) {
-    const int T0 = byteof(top_lo, 0), T1 = byteof(top_lo, 1), T2 = byteof(top_lo, 2), T3 = byteof(top_lo, 3);
-    const int T4 = byteof(top_hi, 0), T5 = byteof(top_hi, 1), T6 = byteof(top_hi, 2), T7 = byteof(top_hi, 3);
-    const int L0 = byteof(left4, 0), L1 = byteof(left4, 1), L2 = byteof(left4, 2), L3 = byteof(left4, 3);
-    const int C = corner;
+    const uint32_t X1 = (top_lo << 8) | uint32_t(corner);                 // C  T0 T1 T2
     switch (mode) {
     case 0: {   // DC
-        const int v = (T0 + T1 + T2 + T3 + L0 + L1 + L2 + L3 + 4) >> 3;
-        row[0] = row[1] = row[2] = row[3] = splat4(v);
+        const uint32_t sum = __builtin_amdgcn_sad_u8(top_lo, 0u, __builtin_amdgcn_sad_u8(left4, 0u, 4u));
+        row[0] = row[1] = row[2] = row[3] = splat4(int(sum >> 3));
         break; }
-    case 1: {   // TM
-        const int L[4] = {L0, L1, L2, L3};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int d = L[r] - C;
-            row[r] = pack4(clampi(d + T0, 0, 255), clampi(d + T1, 0, 255), clampi(d + T2, 0, 255), clampi(d + T3, 0, 255));
-        }
+    case 1:     // TM
+        pred_tm(top_lo, left4, corner, row);
+        break;
+    case 2: {   // VE (smoothed): avg3 over (C T0 T1 T2 | T0..T3 | T1..T4)
+        row[0] = row[1] = row[2] = row[3] = avg3p(X1, top_lo, WP_ALB(top_hi, top_lo, 1));
         break; }
-    case 2: {   // VE (smoothed)
-        const uint32_t v = pack4(avg3(C, T0, T1), avg3(T0, T1, T2), avg3(T1, T2, T3), avg3(T2, T3, T4));
-        row[0] = row[1] = row[2] = row[3] = v;
+    case 3: {   // HE (smoothed): A3[3], A3[2], A3[1], A3[0] with L3 replicated below
+        const uint32_t X0 = WP_PERM(left4, left4, 0x00010203u);            // L3 L2 L1 L0
+        const uint32_t A = avg3p(WP_PERM(X0, X0, 0x02010000u), X0, WP_ALB(X1, X0, 1));
+        row[0] = WP_PERM(A, A, 0x03030303u);
+        row[1] = WP_PERM(A, A, 0x02020202u);
+        row[2] = WP_PERM(A, A, 0x01010101u);
+        row[3] = WP_PERM(A, A, 0x00000000u);
         break; }
-    case 3: {   // HE (smoothed)
-        row[0] = splat4(avg3(C, L0, L1));
-        row[1] = splat4(avg3(L0, L1, L2));
-        row[2] = splat4(avg3(L1, L2, L3));
-        row[3] = splat4(avg3(L2, L3, L3));
-        break; }
-    case 4: {   // RD
-        const int srq = avg3(L3, L2, L1), rqp = avg3(L2, L1, L0), qpa = avg3(L1, L0, C), pab = avg3(L0, C, T0);
-        const int abc = avg3(C, T0, T1), bcd = avg3(T0, T1, T2), cde = avg3(T1, T2, T3);
-        row[0] = pack4(pab, abc, bcd, cde);
-        row[1] = pack4(qpa, pab, abc, bcd);
-        row[2] = pack4(rqp, qpa, pab, abc);
-        row[3] = pack4(srq, rqp, qpa, pab);
+    case 4: {   // RD: row r = A3[4-r .. 7-r]
+        const uint32_t X0 = WP_PERM(left4, left4, 0x00010203u), X2 = WP_ALB(top_hi, top_lo, 3);
+        const uint32_t A0 = avg3p(WP_ALB(X0, X0, 3), X0, WP_ALB(X1, X0, 1));            // A3[1..3] (byte 0 unused)
+        const uint32_t A1 = avg3p(WP_ALB(X1, X0, 3), X1, WP_ALB(X2, X1, 1));            // A3[4..7]
+        row[0] = A1;
+        row[1] = WP_ALB(A1, A0, 3);
+        row[2] = WP_ALB(A1, A0, 2);
+        row[3] = WP_ALB(A1, A0, 1);
         break; }
     case 5: {   // VR
-        const int ab = avg2(C, T0), bc = avg2(T0, T1), cd = avg2(T1, T2), de = avg2(T2, T3);
-        const int rqp = avg3(L2, L1, L0), qpa = avg3(L1, L0, C), pab = avg3(L0, C, T0);
-        const int abc = avg3(C, T0, T1), bcd = avg3(T0, T1, T2), cde = avg3(T1, T2, T3);
-        row[0] = pack4(ab, bc, cd, de);
-        row[1] = pack4(pab, abc, bcd, cde);
-        row[2] = pack4(qpa, ab, bc, cd);
-        row[3] = pack4(rqp, pab, abc, bcd);
+        const uint32_t X0 = WP_PERM(left4, left4, 0x00010203u), X2 = WP_ALB(top_hi, top_lo, 3);
+        const uint32_t n1 = WP_ALB(X2, X1, 1);
+        const uint32_t A0 = avg3p(WP_ALB(X0, X0, 3), X0, WP_ALB(X1, X0, 1));            // A3[2], A3[3] used
+        const uint32_t A1 = avg3p(WP_ALB(X1, X0, 3), X1, n1);                            // A3[4..7]
+        const uint32_t B1 = avg2p(X1, n1);                                               // A2[4..7]
+        row[0] = B1;
+        row[1] = A1;
+        row[2] = WP_ALB(B1, A0, 3);                                                      // A3[3] A2[4] A2[5] A2[6]
+        row[3] = WP_PERM(A1, A0, 0x06050402u);                                           // A3[2] A3[4] A3[5] A3[6]
         break; }
-    case 6: {   // LD
-        const int abc = avg3(T0, T1, T2), bcd = avg3(T1, T2, T3), cde = avg3(T2, T3, T4), def = avg3(T3, T4, T5);
-        const int efg = avg3(T4, T5, T6), fgh = avg3(T5, T6, T7), ghh = avg3(T6, T7, T7);
-        row[0] = pack4(abc, bcd, cde, def);
-        row[1] = pack4(bcd, cde, def, efg);
-        row[2] = pack4(cde, def, efg, fgh);
-        row[3] = pack4(def, efg, fgh, ghh);
+    case 6: {   // LD: row r = A3[6+r .. 9+r], T7 replicated to the right
+        const uint32_t X2 = WP_ALB(top_hi, top_lo, 3), X3 = WP_PERM(top_hi, top_hi, 0x03030303u);
+        const uint32_t A1 = avg3p(WP_ALB(X1, X1, 3), X1, WP_ALB(X2, X1, 1));            // A3[5..7] (byte 0 unused)
+        const uint32_t A2 = avg3p(WP_ALB(X2, X1, 3), X2, WP_ALB(X3, X2, 1));            // A3[8..11]
+        const uint32_t A3 = avg3p(WP_ALB(X3, X2, 3), X3, X3);                            // A3[12] in byte 0
+        row[0] = WP_ALB(A2, A1, 2);
+        row[1] = WP_ALB(A2, A1, 3);
+        row[2] = A2;
+        row[3] = WP_ALB(A3, A2, 1);
         break; }
     case 7: {   // VL
-        const int ab = avg2(T0, T1), bc = avg2(T1, T2), cd = avg2(T2, T3), de = avg2(T3, T4);
-        const int abc = avg3(T0, T1, T2), bcd = avg3(T1, T2, T3), cde = avg3(T2, T3, T4), def = avg3(T3, T4, T5);
-        const int efg = avg3(T4, T5, T6), fgh = avg3(T5, T6, T7);
-        row[0] = pack4(ab, bc, cd, de);
-        row[1] = pack4(abc, bcd, cde, def);
-        row[2] = pack4(bc, cd, de, efg);
-        row[3] = pack4(bcd, cde, def, fgh);
+        const uint32_t X2 = WP_ALB(top_hi, top_lo, 3), X3 = WP_PERM(top_hi, top_hi, 0x03030303u);
+        const uint32_t n1 = WP_ALB(X2, X1, 1), n2 = WP_ALB(X3, X2, 1);
+        const uint32_t A1 = avg3p(WP_ALB(X1, X1, 3), X1, n1), A2 = avg3p(WP_ALB(X2, X1, 3), X2, n2);   // A3[5..7], A3[8..11]
+        const uint32_t B1 = avg2p(X1, n1), B2 = avg2p(X2, n2);                                           // A2[4..7], A2[8..11]
+        row[0] = WP_ALB(B2, B1, 1);                                                      // A2[5..8]
+        row[1] = WP_ALB(A2, A1, 2);                                                      // A3[6..9]
+        row[2] = WP_PERM(A2, WP_ALB(B2, B1, 2), 0x06020100u);                            // A2[6] A2[7] A2[8] A3[10]
+        row[3] = WP_PERM(A2, WP_ALB(A2, A1, 3), 0x07020100u);                            // A3[7] A3[8] A3[9] A3[11]
         break; }
     case 8: {   // HD
-        const int sr = avg2(L3, L2), rq = avg2(L2, L1), qp = avg2(L1, L0), pa = avg2(L0, C);
-        const int srq = avg3(L3, L2, L1), rqp = avg3(L2, L1, L0), qpa = avg3(L1, L0, C), pab = avg3(L0, C, T0);
-        const int abc = avg3(C, T0, T1), bcd = avg3(T0, T1, T2);
-        row[0] = pack4(pa, pab, abc, bcd);
-        row[1] = pack4(qp, qpa, pa, pab);
-        row[2] = pack4(rq, rqp, qp, qpa);
-        row[3] = pack4(sr, srq, rq, rqp);
+        const uint32_t X0 = WP_PERM(left4, left4, 0x00010203u), X2 = WP_ALB(top_hi, top_lo, 3);
+        const uint32_t n0 = WP_ALB(X1, X0, 1);
+        const uint32_t A0 = avg3p(WP_ALB(X0, X0, 3), X0, n0);                            // A3[1..3]
+        const uint32_t A1 = avg3p(WP_ALB(X1, X0, 3), X1, WP_ALB(X2, X1, 1));            // A3[4..6] used
+        const uint32_t B0 = avg2p(X0, n0);                                               // A2[0..3]
+        const uint32_t As = WP_ALB(A1, A0, 1);                                           // A3[1..4]
+        row[0] = WP_PERM(A1, B0, 0x06050403u);                                           // A2[3] A3[4] A3[5] A3[6]
+        row[1] = WP_PERM(As, B0, 0x07030602u);                                           // A2[2] A3[3] A2[3] A3[4]
+        row[2] = WP_PERM(As, B0, 0x06020501u);                                           // A2[1] A3[2] A2[2] A3[3]
+        row[3] = WP_PERM(As, B0, 0x05010400u);                                           // A2[0] A3[1] A2[1] A3[2]
         break; }
-    default: {  // 9: HU
-        const int pq = avg2(L0, L1), qr = avg2(L1, L2), rs = avg2(L2, L3);
-        const int pqr = avg3(L0, L1, L2), qrs = avg3(L1, L2, L3), rss = avg3(L2, L3, L3), sss = L3;
-        row[0] = pack4(pq, pqr, qr, qrs);
-        row[1] = pack4(qr, qrs, rs, rss);
-        row[2] = pack4(rs, rss, sss, sss);
-        row[3] = pack4(sss, sss, sss, sss);
+    default: {  // 9: HU, L3 replicated below
+        const uint32_t X0 = WP_PERM(left4, left4, 0x00010203u);
+        const uint32_t n0 = WP_ALB(X0, X0, 1);                                           // L2 L1 L0 (byte 3 unused)
+        const uint32_t A0 = avg3p(WP_PERM(X0, X0, 0x02010000u), X0, n0);                 // A3[0..2]
+        const uint32_t B0 = avg2p(X0, n0);                                               // A2[0..2]
+        row[0] = WP_PERM(A0, B0, 0x05010602u);                                           // A2[2] A3[2] A2[1] A3[1]
+        row[1] = WP_PERM(A0, B0, 0x04000501u);                                           // A2[1] A3[1] A2[0] A3[0]
+        row[2] = WP_PERM(X0, WP_PERM(A0, B0, 0x00000400u), 0x04040100u);                 // A2[0] A3[0] L3 L3
+        row[3] = WP_PERM(X0, X0, 0x00000000u);                                           // L3 L3 L3 L3
         break; }
     }
 }
@@ -198,17 +233,14 @@ __device__ __forceinline__ void pred4x4(int mode, uint32_t top_lo, uint32_t top_
 // already been through checkTopLeftPred (PredFunc.hx:57-68); dcval is the block-wide DC value.
 __device__ __forceinline__ void pred_large(int mode, uint32_t top4, uint32_t left4, int corner, int dcval, uint32_t (&row)[4]) {
     if (mode == 1) {            // TM
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int d = byteof(left4, r) - corner;
-            row[r] = pack4(clampi(d + byteof(top4, 0), 0, 255), clampi(d + byteof(top4, 1), 0, 255),
-                           clampi(d + byteof(top4, 2), 0, 255), clampi(d + byteof(top4, 3), 0, 255));
-        }
+        pred_tm(top4, left4, corner, row);
     } else if (mode == 2) {     // VE
         row[0] = row[1] = row[2] = row[3] = top4;
     } else if (mode == 3) {     // HE
-#pragma unroll
-        for (int r = 0; r < 4; ++r) row[r] = splat4(byteof(left4, r));
+        row[0] = WP_PERM(left4, left4, 0x00000000u);
+        row[1] = WP_PERM(left4, left4, 0x01010101u);
+        row[2] = WP_PERM(left4, left4, 0x02020202u);
+        row[3] = WP_PERM(left4, left4, 0x03030303u);
     } else {                    // DC and its top/left variants
         row[0] = row[1] = row[2] = row[3] = splat4(dcval);
     }
