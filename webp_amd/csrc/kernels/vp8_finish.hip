@@ -52,34 +52,49 @@ void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* _
     const uint8_t* A = (Ap != nullptr && fr.has_alpha) ? Ap + fr.alpha_off : nullptr;
     uint8_t* const dst = out ? out + fr.argb_off : nullptr;
 
-    // ---- luma rows + ARGB: thread = 4 pixels, wavefront = 256 pixels of one row ----
+    // ---- luma rows + ARGB: thread = 4 pixels x 2 rows (one chroma sample pair: its rounded terms are computed once),
+    //      wavefront = 256 pixels of two rows ----
     const int q = t & 63, px = c0 + 4 * q;
     const int k = (4 * q + shift) >> 4, c4 = (4 * q + shift) & 15;         // source tile / column inside it
     if (k < nt && px < ystride) {
+        const int npx = min(4, width - px);
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int r = pass * 4 + (t >> 6);
-            const int py = 16 * ty - shift + r;
-            if (py < 0 || py >= 16 * mbh) continue;
-            const uint32_t y4 = tiles32[k * (kTileBytes / 4) + 4 * r + (c4 >> 2)];
-            if (Y) WP_NT_STORE(reinterpret_cast<uint32_t*>(Y + size_t(py) * ystride + px), y4);
-            if (dst && py < height && px < width) {
-                const int ci = k * (kTileBytes / 2) + 4 * (r >> 1) + (c4 >> 2);       // 16-bit index of the two chroma samples
+        for (int pass = 0; pass < 2; ++pass) {
+            const int rp = pass * 4 + (t >> 6);                            // row pair inside the tile row (shift is even)
+            const int py0 = 16 * ty - shift + 2 * rp;
+            if (py0 < 0 || py0 >= 16 * mbh) continue;
+            const uint32_t ya = tiles32[k * (kTileBytes / 4) + 8 * rp + (c4 >> 2)];
+            const uint32_t yb = tiles32[k * (kTileBytes / 4) + 8 * rp + 4 + (c4 >> 2)];
+            if (Y) {
+                uint8_t* yp = Y + size_t(py0) * ystride + px;
+                WP_NT_STORE(reinterpret_cast<uint32_t*>(yp), ya);
+                WP_NT_STORE(reinterpret_cast<uint32_t*>(yp + ystride), yb);
+            }
+            if (dst && py0 < height && px < width) {
+                const int ci = k * (kTileBytes / 2) + 4 * rp + (c4 >> 2);  // 16-bit index of the two chroma samples
                 const uint32_t u2 = tiles16[ci + kTileCb / 2], v2 = tiles16[ci + kTileCr / 2];
-                const int npx = min(4, width - px);
-                const size_t pix = size_t(py) * width + px;
-                uint32_t a4 = 0xffffffffu;
-                if (A) {
-                    a4 = 0;
-                    for (int j = 0; j < npx; ++j) a4 |= uint32_t(A[pix + j]) << (8 * j);
-                }
-                const uint4 o = convert_px4(y4, u2, v2, a4);
-                uint8_t* p = dst + pix * 4;
-                if (npx == 4 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-                    { const u32x4 ov4 = {o.x, o.y, o.z, o.w}; WP_NT_STORE(reinterpret_cast<u32x4*>(p), ov4); }
-                } else {
-                    const uint32_t ov[4] = {o.x, o.y, o.z, o.w};
-                    for (int j = 0; j < npx; ++j) reinterpret_cast<uint32_t*>(p)[j] = ov[j];
+                const ChromaTerms t0 = chroma_terms(int(u2 & 0xff), int(v2 & 0xff));
+                const ChromaTerms t1 = chroma_terms(int(u2 >> 8), int(v2 >> 8));
+                const bool any_tie = __builtin_amdgcn_ballot_w64(t0.tie || t1.tie) != 0;
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int py = py0 + rr;
+                    if (py >= height) break;
+                    const size_t pix = size_t(py) * width + px;
+                    uint32_t a4 = 0xffffffffu;
+                    if (A) {
+                        a4 = 0;
+                        for (int j = 0; j < npx; ++j) a4 |= uint32_t(A[pix + j]) << (8 * j);
+                    }
+                    const uint4 o = convert_row4(rr ? yb : ya, t0, t1, a4, any_tie);
+                    uint8_t* p = dst + pix * 4;
+                    if (npx == 4 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                        const u32x4 ov4 = {o.x, o.y, o.z, o.w};
+                        WP_NT_STORE(reinterpret_cast<u32x4*>(p), ov4);
+                    } else {
+                        const uint32_t ov[4] = {o.x, o.y, o.z, o.w};
+                        for (int j = 0; j < npx; ++j) reinterpret_cast<uint32_t*>(p)[j] = ov[j];
+                    }
                 }
             }
         }

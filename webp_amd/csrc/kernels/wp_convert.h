@@ -28,18 +28,30 @@ __device__ __forceinline__ ChromaTerms chroma_terms(int cbv, int crv) {
     return t;
 }
 
-// one pixel -> bytes A,R,G,B in memory order (little-endian dword: A | R<<8 | G<<16 | B<<24)
+// one pixel -> bytes A,R,G,B in memory order (little-endian dword: A | R<<8 | G<<16 | B<<24).  FIX = apply the single
+// Y-dependent tie correction; callers take the FIX = false path when no lane of the wavefront holds the tie pair.
+template <bool FIX>
 __device__ __forceinline__ uint32_t convert_px(int yv, const ChromaTerms& t, uint32_t a) {
-    const int fix = (t.tie && yv >= 111 && yv <= 146) ? 1 : 0;
+    const int fix = (FIX && t.tie && yv >= 111 && yv <= 146) ? 1 : 0;
     return a | uint32_t(clampi(yv + t.r, 0, 255)) << 8 | uint32_t(clampi(yv + t.g - fix, 0, 255)) << 16 | uint32_t(clampi(yv + t.b, 0, 255)) << 24;
 }
 
-// four horizontally adjacent pixels: luma dword, two chroma samples each, four alpha bytes -> 16 bytes of A,R,G,B
+// four horizontally adjacent pixels: luma dword, the chroma terms of its two chroma samples, four alpha bytes
+template <bool FIX>
+__device__ __forceinline__ uint4 convert_row4(uint32_t y4, const ChromaTerms& t0, const ChromaTerms& t1, uint32_t a4) {
+    return make_uint4(convert_px<FIX>(int(y4 & 0xff), t0, a4 & 0xff), convert_px<FIX>(int((y4 >> 8) & 0xff), t0, (a4 >> 8) & 0xff),
+                      convert_px<FIX>(int((y4 >> 16) & 0xff), t1, (a4 >> 16) & 0xff), convert_px<FIX>(int(y4 >> 24), t1, a4 >> 24));
+}
+__device__ __forceinline__ uint4 convert_row4(uint32_t y4, const ChromaTerms& t0, const ChromaTerms& t1, uint32_t a4, bool any_tie) {
+    return any_tie ? convert_row4<true>(y4, t0, t1, a4) : convert_row4<false>(y4, t0, t1, a4);
+}
+
+// luma dword + two chroma samples each (u2, v2: two bytes) -> 16 bytes of A,R,G,B
 __device__ __forceinline__ uint4 convert_px4(uint32_t y4, uint32_t u2, uint32_t v2, uint32_t a4) {
     const ChromaTerms t0 = chroma_terms(int(u2 & 0xff), int(v2 & 0xff));
     const ChromaTerms t1 = chroma_terms(int((u2 >> 8) & 0xff), int((v2 >> 8) & 0xff));
-    return make_uint4(convert_px(int(y4 & 0xff), t0, a4 & 0xff), convert_px(int((y4 >> 8) & 0xff), t0, (a4 >> 8) & 0xff),
-                      convert_px(int((y4 >> 16) & 0xff), t1, (a4 >> 16) & 0xff), convert_px(int(y4 >> 24), t1, a4 >> 24));
+    const bool any_tie = __builtin_amdgcn_ballot_w64(t0.tie || t1.tie) != 0;      // wavefront-uniform
+    return convert_row4(y4, t0, t1, a4, any_tie);
 }
 
 }  // namespace wpk
