@@ -209,6 +209,12 @@ typedef struct wp_parsed wp_parsed;      /* opaque: result of parsing one .webp 
  * Vp8Decoder / Vp8LDecoder; produces the packed buffers above for every frame in the file. */
 int wp_parse(const uint8_t* data, size_t len, wp_parsed** out);
 void wp_parsed_free(wp_parsed* p);
+/* n independent files on up to n_threads host threads (0 = one per hardware thread).  The reference is single-threaded
+ *  but keeps all mutable state in its decoder objects, so one decoder per host thread is what a Haxe caller
+ * would do with `sys.thread`; this is that loop in C++ (the host entropy decode caps end-to-end
+ * throughput long before the kernels do).  out[i] receives the parsed object or NULL, status[i] its wp_status;
+ * returns 0 if every file parsed, else the first failing status (wp_last_error holds that file's message). */
+int wp_parse_batch(int n, const uint8_t* const* data, const size_t* len, int n_threads, wp_parsed** out, int* status);
 /* kind: 0 Yuv420, 1 Argb, 2 Anim (Image.hx:36-46) */
 int wp_parsed_kind(const wp_parsed* p);
 int wp_parsed_width(const wp_parsed* p);

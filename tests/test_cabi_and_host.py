@@ -101,3 +101,24 @@ def test_truncated_stream_is_null_frame():
     with pytest.raises(WebPError) as e:
         parse(bytes(data))
     assert e.value.code == -5
+
+
+def test_parse_batch_threads_match_serial_parse():
+    """wp_parse_batch on several native threads gives byte-identical packed buffers, in order; a bad file fails the call
+    with its index in the message and leaves nothing leaked that the wrapper does not own."""
+    import glob
+    from webp_amd import parse, parse_many
+    from webp_amd._lib import WebPError
+    datas = [open(p, "rb").read() for p in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "inputs", "*.webp")))] * 3
+    many = parse_many(datas, threads=4)
+    assert len(many) == len(datas)
+    for d, m in zip(datas, many):
+        s = parse(d)
+        assert (s.kind, s.width, s.height, len(s.frames)) == (m.kind, m.width, m.height, len(m.frames))
+        for fs, fm in zip(s.frames, m.frames):
+            for which in (0, 1, 2, 3, 4, 5):
+                assert np.array_equal(fs.buf(which, np.uint8), fm.buf(which, np.uint8))
+    bad = list(datas[:5])
+    bad[3] = bad[3][:40]
+    with pytest.raises(WebPError, match="file 3"):
+        parse_many(bad, threads=3)

@@ -77,6 +77,7 @@ def lib():
     L.wp_alpha_unfilter.argtypes = [i32, vp, vp, sz, vp, sz]
     L.wp_parse.argtypes = [vp, sz, ctypes.POINTER(vp)]
     L.wp_parsed_free.argtypes = [vp]
+    L.wp_parse_batch.argtypes = [i32, vp, vp, i32, vp, vp]
     L.wp_parsed_free.restype = None
     for f in ("wp_parsed_kind", "wp_parsed_width", "wp_parsed_height", "wp_parsed_nframes"):
         getattr(L, f).argtypes = [vp]

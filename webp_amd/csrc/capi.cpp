@@ -4,7 +4,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 #include "host/host.h"
@@ -453,6 +455,40 @@ int wp_parse(const uint8_t* data, size_t len, wp_parsed** out) {
     return WP_OK;
 }
 void wp_parsed_free(wp_parsed* p) { delete p; }
+
+int wp_parse_batch(int n, const uint8_t* const* data, const size_t* len, int n_threads, wp_parsed** out, int* status) {
+    if (n < 0 || (n > 0 && (!data || !len || !out))) return fail(WP_ERR_INVALID, "bad argument");
+    if (n == 0) return WP_OK;
+    if (n_threads <= 0) n_threads = int(std::max(1u, std::thread::hardware_concurrency()));
+    n_threads = std::min(n_threads, n);
+    std::vector<int> st(static_cast<size_t>(n), WP_OK);
+    std::vector<std::string> msg(static_cast<size_t>(n));
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            out[i] = nullptr;
+            wp_parsed* p = new (std::nothrow) wp_parsed();
+            if (!p) { st[size_t(i)] = WP_ERR_NOMEM; msg[size_t(i)] = "out of memory"; continue; }
+            int rc;
+            try {
+                rc = (!data[i] && len[i]) ? WP_ERR_INVALID : wp::parse_webp(data[i], len[i], *p, msg[size_t(i)]);
+            } catch (const std::bad_alloc&) {
+                rc = WP_ERR_NOMEM; msg[size_t(i)] = "out of memory";
+            }
+            if (rc) { delete p; st[size_t(i)] = rc; } else out[i] = p;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    int first = WP_OK;
+    for (int i = n - 1; i >= 0; --i) {
+        if (status) status[i] = st[size_t(i)];
+        if (st[size_t(i)]) { first = st[size_t(i)]; g_error = "file " + std::to_string(i) + ": " + msg[size_t(i)]; }
+    }
+    return first;
+}
 int wp_parsed_kind(const wp_parsed* p) { return p ? p->kind : -1; }
 int wp_parsed_width(const wp_parsed* p) { return p ? p->width : 0; }
 int wp_parsed_height(const wp_parsed* p) { return p ? p->height : 0; }

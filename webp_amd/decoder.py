@@ -108,10 +108,13 @@ class ParsedFrame:
 
 
 class ParsedFile:
-    def __init__(self, data: bytes):
+    def __init__(self, data: bytes = None, handle=None):
         L = lib()
-        h = ctypes.c_void_p()
-        check(L.wp_parse(data, len(data), ctypes.byref(h)))
+        if handle is None:
+            h = ctypes.c_void_p()
+            check(L.wp_parse(data, len(data), ctypes.byref(h)))
+        else:
+            h = ctypes.c_void_p(handle)
         self._h = h
         self.kind = L.wp_parsed_kind(h)          # 0 Yuv420, 1 Argb, 2 Anim
         self.width = L.wp_parsed_width(h)
@@ -130,6 +133,22 @@ class ParsedFile:
 def parse(data: bytes) -> ParsedFile:
     """Container walk + entropy decode on the CPU (mirrors the parse half of WebPDecoder.decode)."""
     return ParsedFile(data)
+
+
+def parse_many(datas: List[bytes], threads: int = 0) -> List[ParsedFile]:
+    """parse() for a list of files on `threads` native host threads (0 = all hardware threads); raises on the first bad file."""
+    L = lib()
+    n = len(datas)
+    if n == 0:
+        return []
+    ptrs = (ctypes.c_char_p * n)(*datas)
+    lens = (ctypes.c_size_t * n)(*[len(d) for d in datas])
+    out = (ctypes.c_void_p * n)()
+    status = (ctypes.c_int * n)()
+    rc = L.wp_parse_batch(n, ptrs, lens, threads, out, status)
+    files = [ParsedFile(handle=out[i]) for i in range(n) if out[i]]     # owns (and frees) whatever did parse
+    check(rc)
+    return files
 
 
 # ---------------------------------------------------------------- batch assembly
