@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t avg_px(uint32_t a, uint32_t b) { return (a &
 // ---------------------------------------------------------------- streaming transforms
 __global__ __launch_bounds__(256)
 void vp8l_subtract_green_kernel(const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp) {
-    const wp_vp8l_frame fr = frames[blockIdx.y];
+    const wp_vp8l_frame& fr = frames[blockIdx.y];
     const int idx = fr.n_transforms - 1 - pass;
     if (idx < 0 || fr.t[idx].type != 2) return;
     const Loc loc = locate(fr, idx);
@@ -59,7 +59,7 @@ __device__ __forceinline__ int s8(uint32_t v) { return int(int8_t(v & 0xff)); }
 
 __global__ __launch_bounds__(256)
 void vp8l_cross_color_kernel(const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp, const uint8_t* __restrict__ aux) {
-    const wp_vp8l_frame fr = frames[blockIdx.y];
+    const wp_vp8l_frame& fr = frames[blockIdx.y];
     const int idx = fr.n_transforms - 1 - pass;
     if (idx < 0 || fr.t[idx].type != 1) return;
     const Loc loc = locate(fr, idx);
@@ -83,7 +83,7 @@ void vp8l_cross_color_kernel(const wp_vp8l_frame* __restrict__ frames, int pass,
 
 __global__ __launch_bounds__(256)
 void vp8l_color_indexing_kernel(const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp, const uint8_t* __restrict__ aux) {
-    const wp_vp8l_frame fr = frames[blockIdx.y];
+    const wp_vp8l_frame& fr = frames[blockIdx.y];
     const int idx = fr.n_transforms - 1 - pass;
     if (idx < 0 || fr.t[idx].type != 3) return;
     const Loc loc = locate(fr, idx);
@@ -112,7 +112,7 @@ void vp8l_color_indexing_kernel(const wp_vp8l_frame* __restrict__ frames, int pa
 // final copy into the result slab, with the RGBA -> ARGB byte rotation of WebPDecoder.hx:109-123
 __global__ __launch_bounds__(256)
 void vp8l_finish_kernel(const wp_vp8l_frame* __restrict__ frames, const uint8_t* pix, const uint8_t* tmp, uint8_t* out, int swizzle) {
-    const wp_vp8l_frame fr = frames[blockIdx.y];
+    const wp_vp8l_frame& fr = frames[blockIdx.y];
     const Loc loc = locate(fr, -1);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(loc.in_tmp ? tmp + fr.tmp_off : pix + fr.pix_off);
     uint32_t* dst = reinterpret_cast<uint32_t*>(out + fr.out_off);
@@ -167,6 +167,15 @@ __device__ __forceinline__ uint32_t predict_px(int mode, uint32_t L, uint32_t T,
 struct __attribute__((aligned(4))) Px4 { uint32_t v[4]; };
 constexpr uint32_t kPredSeqShift = 15;      // progress word = (band sequence << 15) | pixels finished in the band's last row
 constexpr int kPredRows = 64;
+// Pixels a lane handles per step.  Every lane walks its own row, so a step touches 64 different rows: with 4 pixels
+// (16 bytes) per row the kernel is bound by the L2 request rate (tools/ubench/row_access.hip: row-strided 16-byte
+// accesses reach 1.1 / 1.7 TB/s for loads / stores, 32-byte ones 3.3 / 1.9 TB/s); with more pixels per step the
+// two-chunk skew between rows costs more idle steps per band.  Measured on 1024 x 1080p, whole chain: 4 px 19.4 ms,
+// 8 px 15.9 ms, 16 px 30.6 ms, 32 px 57.5 ms.
+#ifndef WP_PRED_CHUNK
+#define WP_PRED_CHUNK 8
+#endif
+constexpr int kPC = WP_PRED_CHUNK;
 
 __global__ __launch_bounds__(kWavesPerWG * kWave)
 void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp,
@@ -179,7 +188,7 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
 
     uint32_t seq = 1;
     for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
-        const wp_vp8l_frame fr = frames[f];
+        const wp_vp8l_frame& fr = frames[f];
         const int idx = fr.n_transforms - 1 - pass;
         if (idx < 0 || fr.t[idx].type != 0) continue;
         const Loc loc = locate(fr, idx);
@@ -189,7 +198,7 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
         const int tpr = n_tiles(w, bits);
         const uint8_t* tiles = aux + fr.t[idx].data_off;
         const int n_bands = (h + kPredRows - 1) / kPredRows;
-        const int n_chunks = (w + 3) >> 2;
+        const int n_chunks = (w + kPC - 1) / kPC;
 
         for (int band = 0; band < n_bands; ++band) {
             const uint32_t q = seq + uint32_t(band);
@@ -204,9 +213,9 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
             const uint32_t* above_row = base + (long long)(y > 0 ? y - 1 : 0) * w;
             const uint8_t* tile_row = tiles + 4 * ((row_ok ? y : 0) >> bits) * tpr;
 
-            uint32_t P1[4] = {0, 0, 0, 0};          // my outputs of the previous chunk (what the row below fetches)
-            uint32_t T4[4] = {0, 0, 0, 0};          // row above, pixels of the current chunk
-            uint32_t Tn[4] = {0, 0, 0, 0};          // row above, next chunk (fetched one step early)
+            uint32_t P1[kPC], T4[kPC], Tn[kPC];     // my previous chunk's outputs (what the row below fetches); row above: this chunk, next chunk
+#pragma unroll
+            for (int j = 0; j < kPC; ++j) { P1[j] = 0; T4[j] = 0; Tn[j] = 0; }
             uint32_t TLfirst = 0, Lpx = 0, first_px = 0;
             uint32_t avail = 0;                     // pixels of the row above known to be finished (band boundary)
 
@@ -215,10 +224,10 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                 const bool act = row_ok && k >= 0 && k < n_chunks;
                 // ---- fetch chunk k+1 of the row above: from lane r-1 (its previous chunk), or from memory for the band's first row
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { T4[j] = Tn[j]; Tn[j] = __shfl_up(P1[j], 1); }
+                for (int j = 0; j < kPC; ++j) { T4[j] = Tn[j]; Tn[j] = __shfl_up(P1[j], 1); }
                 if (has_above && c + 1 < n_chunks + 1) {
-                    // lane 0 is about to need pixels up to 4*(c+2)-1 of row y-1
-                    const uint32_t need = uint32_t(min(4 * (c + 2), w));
+                    // lane 0 is about to need pixels up to kPC*(c+2)-1 of row y-1
+                    const uint32_t need = uint32_t(min(kPC * (c + 2), w));
                     if (avail < need) {
                         const uint32_t target = ((q - 1) << kPredSeqShift) | need;
                         uint32_t v;
@@ -228,36 +237,41 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                         avail = (v >> kPredSeqShift) == (q - 1) ? (v & ((1u << kPredSeqShift) - 1u)) : uint32_t(w);
                     }
                     if (r == 0) {
-                        const int x0 = 4 * (c + 1);
+                        const int x0 = kPC * (c + 1);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) Tn[j] = (x0 + j < w) ? above_row[x0 + j] : 0u;
+                        for (int j = 0; j < kPC; ++j) Tn[j] = (x0 + j < w) ? above_row[x0 + j] : 0u;
                         if (c == 0) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) T4[j] = (j < w) ? above_row[j] : 0u;
+                            for (int j = 0; j < kPC; ++j) T4[j] = (j < w) ? above_row[j] : 0u;
                         }
                     }
                 }
                 if (act) {
-                    const int x0 = 4 * k;
-                    uint32_t in[4], out[4];
-                    if (x0 + 4 <= w) {
-                        const Px4 v = *reinterpret_cast<const Px4*>(row + x0);
+                    const int x0 = kPC * k;
+                    uint32_t in[kPC], out[kPC];
+                    if (x0 + kPC <= w) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) in[j] = v.v[j];
+                        for (int g4 = 0; g4 < kPC / 4; ++g4) {
+                            const Px4 v = *reinterpret_cast<const Px4*>(row + x0 + 4 * g4);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) in[4 * g4 + j] = v.v[j];
+                        }
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) in[j] = (x0 + j < w) ? row[x0 + j] : 0u;
+                        for (int j = 0; j < kPC; ++j) in[j] = (x0 + j < w) ? row[x0 + j] : 0u;
                     }
-                    const int tile_mode = tile_row[4 * (x0 >> bits) + 1] & 15;   // a 4-pixel chunk never straddles a tile (bits >= 2)
+                    int tile_mode = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < kPC; ++j) {
                         const int x = x0 + j;
+                        // a 4-pixel group never straddles a tile (bits >= 2); tiles beyond the row's end are never read
+                        if ((j & 3) == 0) tile_mode = tile_row[4 * (min(x, w - 1) >> bits) + 1] & 15;
                         uint32_t pred;
                         if (y == 0) pred = x == 0 ? 0xff000000u : Lpx;            // first row: black / L (:40-53)
                         else if (x == 0) pred = T4[0];                            // first column: T (:61-64)
                         else {
                             const uint32_t TL = j ? T4[j - 1] : TLfirst;
-                            uint32_t TR = j < 3 ? T4[j + 1] : Tn[0];
+                            uint32_t TR = j < kPC - 1 ? T4[j + 1] : Tn[0];
                             if (x == w - 1) TR = first_px;                        // linear addressing: top+4 is the row's own first pixel
                             pred = predict_px(tile_mode, Lpx, T4[j], TL, TR);
                         }
@@ -265,23 +279,26 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                         if (x < w) Lpx = out[j];
                         if (x == 0) first_px = out[j];
                     }
-                    if (x0 + 4 <= w) {
-                        Px4 v;
+                    if (x0 + kPC <= w) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v.v[j] = out[j];
-                        *reinterpret_cast<Px4*>(row + x0) = v;
+                        for (int g4 = 0; g4 < kPC / 4; ++g4) {
+                            Px4 v;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v.v[j] = out[4 * g4 + j];
+                            *reinterpret_cast<Px4*>(row + x0 + 4 * g4) = v;
+                        }
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) if (x0 + j < w) row[x0 + j] = out[j];
+                        for (int j = 0; j < kPC; ++j) if (x0 + j < w) row[x0 + j] = out[j];
                     }
-                    TLfirst = T4[3];
+                    TLfirst = T4[kPC - 1];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) P1[j] = out[j];
+                    for (int j = 0; j < kPC; ++j) P1[j] = out[j];
                 }
                 if (has_below) {
                     const int k_last = c - 2 * (kPredRows - 1);
-                    if (k_last >= 0 && ((k_last & 3) == 3 || k_last == n_chunks - 1))
-                        publish_progress(&progress[wave], (q << kPredSeqShift) | uint32_t(min(4 * (k_last + 1), w)));
+                    if (k_last >= 0 && (((k_last + 1) * kPC) % 16 == 0 || k_last == n_chunks - 1))
+                        publish_progress(&progress[wave], (q << kPredSeqShift) | uint32_t(min(kPC * (k_last + 1), w)));
                 }
             }
         }
@@ -296,7 +313,7 @@ __device__ __forceinline__ uint32_t alpha_src(const uint8_t* src, bool rgba, lon
 // the first column of the other rows a running sum along y (:364-370, :380-384, :389-396).
 __global__ __launch_bounds__(256)
 void alpha_copy_kernel(const wp_alpha_frame* __restrict__ frames, const uint8_t* __restrict__ src, uint8_t* alpha) {
-    const wp_alpha_frame fr = frames[blockIdx.y];
+    const wp_alpha_frame& fr = frames[blockIdx.y];
     const uint8_t* s = src + fr.src_off;
     uint8_t* d = alpha + fr.dst_off;
     const long long total = (long long)fr.width * fr.height;
@@ -308,7 +325,7 @@ void alpha_copy_kernel(const wp_alpha_frame* __restrict__ frames, const uint8_t*
 // vertical filter, stage 1: running sum along row 0 (one wavefront per frame, 64 bytes per round).
 __global__ __launch_bounds__(64)
 void alpha_row0_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* alpha) {
-    const wp_alpha_frame fr = frames[blockIdx.x];
+    const wp_alpha_frame& fr = frames[blockIdx.x];
     if (fr.filter != 2) return;
     uint8_t* a = alpha + fr.dst_off;
     const int lane = threadIdx.x;
@@ -326,7 +343,7 @@ void alpha_row0_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* alpha
 // vertical filter, stage 2: running sum down every column (:383-385); thread = column, coalesced rows.
 __global__ __launch_bounds__(256)
 void alpha_columns_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* alpha) {
-    const wp_alpha_frame fr = frames[blockIdx.y];
+    const wp_alpha_frame& fr = frames[blockIdx.y];
     if (fr.filter != 2) return;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= fr.width) return;
@@ -350,7 +367,7 @@ void alpha_columns_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* al
 // 64-byte blocks fetched one block ahead.
 __global__ __launch_bounds__(64)
 void alpha_unfilter_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* alpha) {
-    const wp_alpha_frame fr = frames[blockIdx.x];
+    const wp_alpha_frame& fr = frames[blockIdx.x];
     const int w = fr.width, h = fr.height, filter = fr.filter;
     if (filter != 1 && filter != 3) return;
     uint8_t* a = alpha + fr.dst_off;

@@ -98,6 +98,14 @@ class ParsedFrame:
         self._owner = owner
         self._index = index
 
+    _VP8L_META = ("vp8l_width", "vp8l_height", "transforms", "alpha_width", "alpha_height", "alpha_transforms")
+
+    def __getattr__(self, name):          # only called when normal lookup fails
+        if name in ParsedFrame._VP8L_META:
+            _load_vp8l_meta(self)
+            return self.__dict__[name]
+        raise AttributeError(name)
+
     def buf(self, which, dtype=np.uint8):
         n = ctypes.c_size_t()
         p = lib().wp_parsed_frame_buf(self._owner._h, self._index, which, ctypes.byref(n))
@@ -262,8 +270,8 @@ def _frame_transforms(f: ParsedFrame):
     return f.transforms
 
 
-# transform metadata is fetched lazily through a tiny extra query encoded in wp_parsed_frame_buf lens;
-# the native side exposes it via wp_parsed_frame_info2 (see capi.cpp).
+# VP8L metadata (sizes + transform lists of the frame's own image and of its VP8L-coded alpha image) comes from
+# wp_parsed_frame_vp8l_meta; ParsedFrame loads it on first access of one of these attributes.
 def _load_vp8l_meta(f: ParsedFrame):
     L = lib()
     meta = (ctypes.c_int32 * 32)()
