@@ -75,7 +75,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("WEBP_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(device))
 
