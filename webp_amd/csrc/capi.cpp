@@ -88,6 +88,17 @@ int check_vp8_work(int n, const wp_vp8_frame* f, const void* d_work, size_t work
     return WP_OK;
 }
 
+// The wavefront kernels number the bands a workgroup processes in a 20-bit field of their LDS progress words
+// (kernels/wp_device.h: seq << 12 | macroblocks); a launch therefore takes at most as many frames as keep that count
+// below 2^19 for the smallest grid that can occur (one workgroup per CU) -- far beyond any batch that fits in HBM, but
+// checked rather than assumed.
+int frames_per_launch(int n, const wp_vp8_frame* f) {
+    long long max_bands = 1;
+    for (int i = 0; i < n; ++i) max_bands = std::max(max_bands, (long long)(f[i].mbh + 3) / 4);
+    const long long per_wg = std::max(1LL, (1LL << 19) / max_bands);
+    return int(std::min<long long>(n, per_wg * std::max(1, g_cus)));
+}
+
 struct FinishGeom { int chunks = 1, rows = 1; };
 FinishGeom finish_geom(int n, const wp_vp8_frame* f) {
     FinishGeom g;
@@ -170,8 +181,11 @@ int wp_vp8_recon_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, cons
     Vp8Work w;
     rc = check_vp8_work(n, fh, d_work, work_bytes, w); if (rc) return rc;
     uint8_t* work = static_cast<uint8_t*>(d_work);
-    const int e = wpk_launch_vp8_recon(n, g_cus, fd, d_mb, d_coeff, work, hipStream_t(stream));
-    if (e) return hip_fail(hipError_t(e), "vp8_recon launch");
+    const int per = frames_per_launch(n, fh);
+    for (int first = 0; first < n; first += per) {
+        const int e = wpk_launch_vp8_recon(std::min(per, n - first), g_cus, fd + first, d_mb, d_coeff, work, hipStream_t(stream));
+        if (e) return hip_fail(hipError_t(e), "vp8_recon launch");
+    }
     if (planes) return launch_finish(n, fh, fd, work, w, 1, d_y, d_u, d_v, nullptr, nullptr, hipStream_t(stream));
     return WP_OK;
 }
@@ -197,8 +211,11 @@ int wp_vp8_loopfilter_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd,
             if (e) return hip_fail(hipError_t(e), "vp8_tile launch");
         }
     }
-    const int e = wpk_launch_vp8_filter(n, g_cus, fd, d_filt, work, work + w.r_bytes, hipStream_t(stream));
-    if (e) return hip_fail(hipError_t(e), "vp8_filter launch");
+    const int per = frames_per_launch(n, fh);
+    for (int first = 0; first < n; first += per) {
+        const int e = wpk_launch_vp8_filter(std::min(per, n - first), g_cus, fd + first, d_filt, work, work + w.r_bytes, hipStream_t(stream));
+        if (e) return hip_fail(hipError_t(e), "vp8_filter launch");
+    }
     if (planes) return launch_finish(n, fh, fd, work, w, 0, d_y, d_u, d_v, nullptr, nullptr, hipStream_t(stream));
     return WP_OK;
 }
