@@ -122,3 +122,26 @@ def test_parse_batch_threads_match_serial_parse():
     bad[3] = bad[3][:40]
     with pytest.raises(WebPError, match="file 3"):
         parse_many(bad, threads=3)
+
+
+def test_vp8_plan_fills_tile_bases_and_workspace_size():
+    """wp_vp8_plan needs no GPU: stile_base is the running sum of (mbw+1)*(mbh+1) and the workspace holds one 384-byte R
+    tile per MB record slot plus the S tiles; bad descriptors are refused."""
+    from webp_amd._lib import Vp8Frame, WebPError, check, lib
+    dims = [(120, 68), (1, 1), (7, 3)]
+    desc = (Vp8Frame * len(dims))()
+    mb = 0
+    for d, (w, h) in zip(desc, dims):
+        d.width, d.height, d.mbw, d.mbh, d.mb_base = 16 * w, 16 * h, w, h, mb
+        mb += w * h
+    work = ctypes.c_uint64(0)
+    check(lib().wp_vp8_plan(len(dims), desc, ctypes.byref(work)))
+    st = 0
+    for d, (w, h) in zip(desc, dims):
+        assert d.stile_base == st
+        st += (w + 1) * (h + 1)
+    r_bytes = (384 * mb + 255) // 256 * 256
+    assert work.value == r_bytes + 384 * st
+    desc[1].mbw = 0
+    with pytest.raises(WebPError, match="bad wp_vp8_frame at index 1"):
+        check(lib().wp_vp8_plan(len(dims), desc, ctypes.byref(work)))

@@ -35,12 +35,9 @@ struct ReconWaveLds {
 
 __device__ __forceinline__ uint32_t& tile32(uint8_t* row, int col) { return *reinterpret_cast<uint32_t*>(row + col); }
 
-__device__ __forceinline__ int avg3(int a, int b, int c) { return (a + 2 * b + c + 2) >> 2; }
-__device__ __forceinline__ int avg2(int a, int b) { return (a + b + 1) >> 1; }
 __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) { return uint32_t(a) | uint32_t(b) << 8 | uint32_t(c) << 16 | uint32_t(d) << 24; }
-// byte 0 of v in all four bytes (one v_perm_b32; a multiply by 0x01010101 would be a quarter-rate v_mul_lo_u32)
+// byte 0 of v in all four bytes (one v_perm_b32)
 __device__ __forceinline__ uint32_t splat4(int v) { return __builtin_amdgcn_perm(uint32_t(v), uint32_t(v), 0u); }
-__device__ __forceinline__ int byteof(uint32_t v, int i) { return int((v >> (8 * i)) & 0xff); }
 
 // Wrapping 32-bit multiply, arithmetic >> 16 (Vp8Decoder.hx:913-914).  The operands of every call fit in 24
 // signed bits (coefficients are int16, the WHT DC < 2^18, first-pass outputs < 2^18, the constants < 2^17), so the low
