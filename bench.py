@@ -139,6 +139,17 @@ def main():
                 "pipeline_alg_bytes_per_px": round((in_bytes + yuv_bytes + argb_bytes) / px_per_step, 3),
                 "pipeline_frac": round((in_bytes + yuv_bytes + argb_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
+    # measured device-to-device copy bandwidth on this GPU (read + write bytes), the practical HBM ceiling beside the nominal peak
+    nbytes = min(db.argb.numel() // 2, 1 << 31)
+    src_t, dst_t = db.argb[:nbytes], db.argb[nbytes:2 * nbytes]
+    dst_t.copy_(src_t); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        dst_t.copy_(src_t)
+    e1.record(); e1.synchronize()
+    roofline["measured_copy_GBs"] = round(5 * 2 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
     line = {"metric": "decoded Mpix/s (whole node) for batched 1080p lossy WebP", "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32/u8",
