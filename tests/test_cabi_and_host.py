@@ -145,3 +145,35 @@ def test_vp8_plan_fills_tile_bases_and_workspace_size():
     desc[1].mbw = 0
     with pytest.raises(WebPError, match="bad wp_vp8_frame at index 1"):
         check(lib().wp_vp8_plan(len(dims), desc, ctypes.byref(work)))
+
+
+def test_mutated_files_are_rejected_or_parsed_without_crashing():
+    """Random truncations / byte flips of the fixtures: wp_parse either returns a negative status with a message or a
+    consistent object (tools/fuzz/run.sh runs the same mutations under ASan + UBSan)."""
+    import glob
+    from webp_amd._lib import lib
+    rng = np.random.default_rng(7)
+    L = lib()
+    n_ok = n_bad = 0
+    for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "inputs", "*.webp"))):
+        d = np.frombuffer(open(path, "rb").read(), np.uint8)
+        for it in range(40):
+            m = d.copy()
+            kind = it % 3
+            if kind == 0:
+                m = m[:rng.integers(0, m.size + 1)]
+            elif kind == 1:
+                m[rng.integers(0, m.size, 4)] = rng.integers(0, 256, 4)
+            else:
+                m[rng.integers(0, min(m.size, 64), 2)] = rng.integers(0, 256, 2)
+            data = m.tobytes()
+            h = ctypes.c_void_p()
+            rc = L.wp_parse(data, len(data), ctypes.byref(h))
+            if rc == 0:
+                assert h.value and L.wp_parsed_nframes(h) >= 1 and L.wp_parsed_width(h) > 0
+                L.wp_parsed_free(h)
+                n_ok += 1
+            else:
+                assert rc < 0 and not h.value
+                n_bad += 1
+    assert n_ok > 0 and n_bad > 0

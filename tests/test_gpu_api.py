@@ -74,3 +74,34 @@ def test_errors_surface_reference_messages():
         WebPDecoder.decode(b"RIFX\x00\x00\x00\x00WEBP")
     with pytest.raises(WebPError, match="no VP8/VP8L chunk found"):
         WebPDecoder.decode(b"RIFF\x04\x00\x00\x00WEBP")
+
+
+@pytest.mark.parametrize("name", ["1", "4", "a"])
+def test_corrupted_token_data_decodes_like_the_oracle(name):
+    """Byte flips inside the token partitions still parse (the boolean decoder never fails before EOF) but yield arbitrary
+    modes and coefficients: the GPU path must agree with the oracle on them bit for bit -- or both must reject."""
+    from oracle import oracle
+    from webp_amd import WebPDecoder, Tools, WebPError
+    rng = np.random.default_rng(hash(name) % 1000)
+    d = np.frombuffer(golden_input(name), np.uint8)
+    checked = 0
+    for it in range(10):
+        m = d.copy()
+        pos = rng.integers(int(0.4 * m.size), m.size, 3)
+        m[pos] = rng.integers(0, 256, 3)
+        data = m.tobytes()
+        try:
+            want = oracle.decode(data)
+        except Exception:
+            want = None
+        try:
+            got = Tools.framesToArgb(WebPDecoder.decode(data))
+        except WebPError:
+            got = None
+        assert (want is None) == (got is None), "iteration %d: one side rejected the stream" % it
+        if want is not None:
+            exp = want["to_argb"] if "to_argb" in want else None
+            if exp is not None:
+                assert np.array_equal(got[0], exp), "iteration %d" % it
+                checked += 1
+    assert checked > 0

@@ -105,3 +105,20 @@ def test_random_packed_frames(filter_type, extreme):
                 i, w, h, name, bad.size, bad[0] // stride, bad[0] % stride, g[bad[0]], exp[name][bad[0]])
         want = oracle.yuv420_to_argb(exp["y"], 16 * w, exp["u"], exp["v"], 8 * w, None, d.width, d.height)
         assert np.array_equal(argb[d.argb_off:d.argb_off + 4 * d.width * d.height], want), "frame %d ARGB" % i
+
+
+def test_out_of_range_block_index_is_refused():
+    """The host-pointer entry point validates the coefficient-block indices of every MB record before any launch."""
+    from webp_amd._lib import Vp8Frame, WebPError, check, lib
+    rng = np.random.default_rng(5)
+    mb, coeff, filt = make_frame(rng, 3, 2, False)
+    desc = (Vp8Frame * 1)()
+    d = desc[0]
+    d.width, d.height, d.mbw, d.mbh, d.filter_type = 48, 32, 3, 2, 2
+    mb = mb.copy()
+    mb[4 * 5 + 2] |= 1                      # make sure the last MB stores a block ...
+    mb[4 * 5 + 3] = coeff.size // 16        # ... and point it past the end of the coefficient array
+    y = np.zeros(256 * 6, np.uint8); u = np.zeros(64 * 6, np.uint8); v = np.zeros(64 * 6, np.uint8)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    with pytest.raises(WebPError, match="coefficient block index out of range in frame 0, macroblock 5"):
+        check(lib().wp_vp8_decode_to_argb(1, desc, p(mb), 6, p(filt), p(coeff), coeff.size // 16, p(y), p(u), p(v), None, None))

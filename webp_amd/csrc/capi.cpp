@@ -355,6 +355,16 @@ int wp_vp8_decode_to_argb(int n, const wp_vp8_frame* frames, const uint32_t* mb,
     for (int i = 0; i < n; ++i) {
         if (size_t(frames[i].mb_base) + size_t(frames[i].mbw) * frames[i].mbh > n_mb) return fail(WP_ERR_INVALID, "mb_base out of range");
         if (frames[i].coeff_base > n_coeff_blocks) return fail(WP_ERR_INVALID, "coeff_base out of range");
+        // the kernels follow the block indices in the MB records: check them here, where the records are host memory
+        // (the _dev entry points take device buffers on trust)
+        const size_t avail = n_coeff_blocks - size_t(frames[i].coeff_base);
+        if (avail && !coeff) return fail(WP_ERR_INVALID, "null coefficient array");
+        const uint32_t* rec = mb + size_t(frames[i].mb_base) * WP_MB_WORDS;
+        for (size_t m = 0, e = size_t(frames[i].mbw) * frames[i].mbh; m < e; ++m, rec += WP_MB_WORDS) {
+            const size_t cnt = size_t(__builtin_popcount(rec[2] & 0x00ffffffu)) + ((rec[2] >> WP_MB_WHT_BIT) & 1u);
+            if (cnt && size_t(rec[3]) + cnt > avail)
+                return fail(WP_ERR_INVALID, "coefficient block index out of range in frame " + std::to_string(i) + ", macroblock " + std::to_string(m));
+        }
     }
     const Vp8Extents ex = vp8_extents(n, frames);
     std::vector<wp_vp8_frame> planned(frames, frames + n);      // the caller's descriptors stay untouched
