@@ -1,0 +1,300 @@
+// Loop filter of one band (4 macroblock rows) of one frame by one wavefront: device code shared by the stand-alone loop
+// filter kernel (vp8_filter.hip) and the fused lossy kernel (vp8_lossy.hip).  See vp8_filter.hip for the design.
+#pragma once
+#include "wp_device.h"
+
+namespace wpk {
+
+struct alignas(16) FilterTile {
+    uint8_t y[24][48];          // rows 0..7: the 8 rows above, 8..23: MB rows; cols: MB slot (x & 1) * 16; pitch 48 = 12 dwords:
+                                // the 16-byte row accesses (lane = row) of 8 consecutive lanes cover all 32 banks once
+    uint8_t c[2][12][16];       // rows 0..3: above, 4..11: MB rows; cols: slot (x & 1) * 8
+    uint8_t pad[16];            // 1552 B = 388 dwords: the four groups' tiles start 4 banks apart
+};
+struct alignas(16) FilterWaveLds {
+    FilterTile tile[kBandRows];
+    alignas(16) uint8_t ring_y[kBandRows][8][64];      // ring_y[g][row][abs_col & 63]: 8 bottom luma rows of the MB row above group g
+    uint8_t ring_c[kBandRows][2][4][32];   // same for Cb / Cr (4 rows)
+};
+
+__device__ __forceinline__ uint2& t64(uint8_t* p) { return *reinterpret_cast<uint2*>(p); }
+__device__ __forceinline__ uint4& t128(uint8_t* p) { return *reinterpret_cast<uint4*>(p); }
+__device__ __forceinline__ void unpack4(uint32_t w, int* v) { v[0] = w & 0xff; v[1] = (w >> 8) & 0xff; v[2] = (w >> 16) & 0xff; v[3] = w >> 24; }
+__device__ __forceinline__ uint32_t pack4i(const int* v) { return uint32_t(v[0]) | uint32_t(v[1]) << 8 | uint32_t(v[2]) << 16 | uint32_t(v[3]) << 24; }
+__device__ __forceinline__ uint32_t& t32(uint8_t* p) { return *reinterpret_cast<uint32_t*>(p); }
+// |a - b| for non-negative a, b in ONE instruction (v_sad_u32 with a zero accumulator) instead of sub, sub, max:
+// both kernels are bound by VALU issue, and most integer VALU instructions cost 4 cycles per wavefront
+// (tools/ubench/valu_rate.hip), so instruction count is what matters.
+__device__ __forceinline__ int absdiff(int a, int b) {
+    int d;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ int clamp127(int v) { return clampi(v, -127, 127); }   // Filter.hx:16-18 (symmetric)
+__device__ __forceinline__ int clamp15(int v) { return clampi(v, -15, 15); }      // Filter.hx:20-22
+__device__ __forceinline__ int clamp255(int v) { return clampi(v, 0, 255); }
+
+// The edge filters are written branch-free (every lane of the wavefront handles a different pixel
+// position, so all branches would be executed anyway) and take / return values, never references:
+// the sample arrays then stay in registers.  "Not filtered" is expressed as zero deltas, which
+// leaves the 0..255 samples unchanged through clamp255.
+
+// filter2, one position (Filter.hx:29-50): returns the deltas for p0 (added) and q0 (subtracted)
+__device__ __forceinline__ void simple_edge(int p1, int& p0, int& q0, int q1, int level) {
+    const bool on = (absdiff(p0, q0) << 1) + (absdiff(p1, q1) >> 1) <= level;
+    const int a = 3 * (q0 - p0) + clamp127(p1 - q1);
+    const int a1 = on ? clamp15((a + 4) >> 3) : 0;
+    const int a2 = on ? clamp15((a + 3) >> 3) : 0;
+    p0 = clamp255(p0 + a2);
+    q0 = clamp255(q0 - a1);
+}
+
+// filter246, one position (Filter.hx:53-111).  FOUR = inner edge (4-pixel filter), else MB edge (6-pixel).
+template <bool FOUR>
+__device__ __forceinline__ void normal_edge(int p3, int& p2, int& p1, int& p0, int& q0, int& q1, int& q2, int q3,
+                                            int level, int ilevel, int hlevel) {
+    const int d10 = absdiff(p1, p0), e10 = absdiff(q1, q0);
+    const int worst = max(max(max(absdiff(p3, p2), absdiff(p2, p1)), max(d10, e10)), max(absdiff(q2, q1), absdiff(q3, q2)));
+    const bool on = (absdiff(p0, q0) << 1) + (absdiff(p1, q1) >> 1) <= level && worst <= ilevel;
+    const bool hev = d10 > hlevel || e10 > hlevel;
+    const int base = 3 * (q0 - p0);
+    const int outer = clamp127(p1 - q1);
+    if (FOUR) {
+        const int a = base + (hev ? outer : 0);
+        const int a1 = on ? clamp15((a + 4) >> 3) : 0;
+        const int a2 = on ? clamp15((a + 3) >> 3) : 0;
+        const int a3 = hev ? 0 : (a1 + 1) >> 1;            // a1 == 0 when !on
+        p1 = clamp255(p1 + a3);
+        p0 = clamp255(p0 + a2);
+        q0 = clamp255(q0 - a1);
+        q1 = clamp255(q1 - a3);
+    } else {
+        const int w = base + outer;
+        const int a = clamp127(w);
+        const int c1 = (27 * a + 63) >> 7, c2 = (18 * a + 63) >> 7, c3 = (9 * a + 63) >> 7;
+        const int dp0 = on ? (hev ? clamp15((w + 3) >> 3) : c1) : 0;
+        const int dq0 = on ? (hev ? clamp15((w + 4) >> 3) : c1) : 0;
+        const int d1 = (on && !hev) ? c2 : 0;
+        const int d2 = (on && !hev) ? c3 : 0;
+        p2 = clamp255(p2 + d2);
+        p1 = clamp255(p1 + d1);
+        p0 = clamp255(p0 + dp0);
+        q0 = clamp255(q0 - dq0);
+        q1 = clamp255(q1 - d1);
+        q2 = clamp255(q2 - d2);
+    }
+}
+
+// One line of N = 4 + 16 (luma) or 4 + 8 (chroma) samples crossing the MB edge at index 4 and the
+// inner edges at 8 (and 12, 16 for luma).  Order as in the reference: MB edge first, then inner edges.
+// Edges are written out with constant indices so that the sample array stays in registers.
+template <int N>
+__device__ __forceinline__ void filter_line(int (&v)[N], bool simple, bool mb_edge, bool inner, int level, int ilevel, int hlevel) {
+    if (simple) {
+        if (mb_edge) simple_edge(v[2], v[3], v[4], v[5], level + 4);
+        if (inner) {
+            simple_edge(v[6], v[7], v[8], v[9], level);
+            if constexpr (N == 20) {
+                simple_edge(v[10], v[11], v[12], v[13], level);
+                simple_edge(v[14], v[15], v[16], v[17], level);
+            }
+        }
+    } else {
+        if (mb_edge) normal_edge<false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], level + 4, ilevel, hlevel);
+        if (inner) {
+            normal_edge<true>(v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], level, ilevel, hlevel);
+            if constexpr (N == 20) {
+                normal_edge<true>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], level, ilevel, hlevel);
+                normal_edge<true>(v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19], level, ilevel, hlevel);
+            }
+        }
+    }
+}
+
+// One band.  `q` is the band's sequence number in this workgroup (band q-1 is the band above when band > 0), `progress`
+// the workgroup's LDS progress words (one per wavefront, W of them).  The caller has made sure that the band's R tiles
+// are complete and visible.
+template <int W>
+__device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, int n_bands, uint32_t q, int wave, uint32_t* progress,
+                                            FilterWaveLds& lds, const uint32_t* __restrict__ filt, const uint8_t* __restrict__ Rp, uint8_t* Sp) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4;
+    const int l = lane & 15;
+    FilterTile& T = lds.tile[g];
+    // lane roles in the row-wise phases
+    const int lp = l >> 3, lr = l & 7;                    // chroma plane / chroma row
+    const int hr = l >> 1, hh = l & 1;                    // hand-over: luma row 0..7, 8-byte half
+    const int hcr = (l >> 1) & 3;                         // hand-over: chroma row 0..3 (plane = lp, 4-byte half = hh)
+    const int mbw = fr.mbw, mbh = fr.mbh;
+    const bool simple = fr.filter_type == 1;
+    const uint8_t* const R = Rp + size_t(fr.mb_base) * kTileBytes;
+    uint8_t* const S = Sp + size_t(fr.stile_base) * kTileBytes;
+    const int spitch = mbw + 1;
+    WP_PROF_DECL;
+    const int y = band * kBandRows + g;
+    const bool row_ok = y < mbh;
+    const bool has_above = band > 0;
+    const bool has_below = band + 1 < n_bands;
+    const int prev_wave = (wave + W - 1) % W;
+    const int rows_here = min(kBandRows, mbh - band * kBandRows);
+    const int n_steps = mbw + 2 * (rows_here - 1);
+    const bool last_row = g == rows_here - 1;             // its bottom rows leave the band through the S tiles
+
+    // Everything a step reads from global memory is fetched one step ahead (registers), so no global
+    // round trip sits on a step's critical path: the MB's own tile and filter record, and -- for the
+    // band's first row -- the eight rows above (which makes this band trail the one above by 3 MBs).
+    const int yy = row_ok ? y : 0;
+    const uint8_t* rrow = R + size_t(yy) * mbw * kTileBytes;                 // R tiles of this MB row
+    uint8_t* srow = S + size_t(yy) * spitch * kTileBytes;                    // S tiles of tile row y
+    const uint32_t* frow = filt + size_t(fr.mb_base) + size_t(yy) * mbw;
+    const bool top_lane = has_above && g == 0;
+    // above rows of MB x: S(x, y) bytes 8..15 of rows 0..7 (cols 0..7) and S(x+1, y) bytes 0..7 (cols 8..15)
+    const uint8_t* trow_y = srow + size_t(hh) * kTileBytes + 16 * hr + 8 * (1 - hh);
+    const uint8_t* trow_c = srow + size_t(hh) * kTileBytes + kTileCb + 64 * lp + 8 * hcr + 4 * (1 - hh);
+    uint4 nx_y = make_uint4(0, 0, 0, 0);
+    uint2 nx_c = make_uint2(0, 0), nx_ty = make_uint2(0, 0);
+    uint32_t nx_fp = 0, nx_tc = 0;
+    if (has_above) wait_progress(&progress[prev_wave], ((q - 1) << kSeqShift) | uint32_t(min(2, mbw)));
+    if (row_ok && g == 0) {
+        nx_y = ld_nt(reinterpret_cast<const uint4*>(rrow + 16 * l));
+        nx_c = ld_nt(reinterpret_cast<const uint2*>(rrow + kTileCb + 8 * l));
+        nx_fp = frow[0];
+        if (top_lane) { nx_ty = *reinterpret_cast<const uint2*>(trow_y); nx_tc = *reinterpret_cast<const uint32_t*>(trow_c); }
+    }
+    settle(nx_y); settle(nx_ty); settle(nx_c); settle(nx_tc); settle(nx_fp);
+    uint32_t pending_publish = 0;
+
+    WP_PROF_MARK(9);
+    for (int s = 0; s < n_steps; ++s) {
+        WP_PROF_MARK(8);
+        const int x = s - 2 * g;
+        const bool act = row_ok && x >= 0 && x < mbw;
+        const uint4 cur_y = nx_y;
+        const uint2 cur_c = nx_c, cur_ty = nx_ty;
+        const uint32_t fp = nx_fp, cur_tc = nx_tc;
+        if (has_above && s + 1 < mbw)
+            wait_progress(&progress[prev_wave], ((q - 1) << kSeqShift) | uint32_t(min(s + 3, mbw)));
+        if (row_ok && x + 1 >= 0 && x + 1 < mbw) {
+            const size_t o = size_t(x + 1) * kTileBytes;
+            nx_y = ld_nt(reinterpret_cast<const uint4*>(rrow + o + 16 * l));
+            nx_c = ld_nt(reinterpret_cast<const uint2*>(rrow + o + kTileCb + 8 * l));
+            nx_fp = frow[x + 1];
+            if (top_lane) { nx_ty = *reinterpret_cast<const uint2*>(trow_y + o); nx_tc = *reinterpret_cast<const uint32_t*>(trow_c + o); }
+        }
+
+        WP_PROF_MARK(0);
+        const int level = int(fp & 0xff), ilevel = int((fp >> 8) & 0xff), hlevel = int((fp >> 16) & 0xff);
+        const bool inner = (fp >> 24) & 1;
+        const bool do_filter = act && level != 0;                   // `if (f.level == 0) continue` (:421, :449)
+        const int cb = 16 * (x & 1), pb = 16 - cb;                  // luma column base of this MB's slot / the previous MB's
+        const int cb8 = cb >> 1, pb8 = pb >> 1;
+        if (act) {
+            // ---- 1. own macroblock (nobody has touched it yet) and the rows above it ----
+            t128(&T.y[8 + l][cb]) = cur_y;
+            t64(&T.c[lp][4 + lr][cb8]) = cur_c;
+            if (y > 0) {
+                if (g > 0) {
+                    t64(&T.y[hr][cb + 8 * hh]) = t64(&lds.ring_y[g][hr][(16 * x + 8 * hh) & 63]);
+                    t32(&T.c[lp][hcr][cb8 + 4 * hh]) = t32(&lds.ring_c[g][lp][hcr][(8 * x + 4 * hh) & 31]);
+                } else {
+                    t64(&T.y[hr][cb + 8 * hh]) = cur_ty;
+                    t32(&T.c[lp][hcr][cb8 + 4 * hh]) = cur_tc;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        WP_PROF_MARK(1);
+        if (do_filter) {
+            // ---- 2a. vertical edges: lane = pixel row; columns -4..15 relative to the MB ----
+            {
+                int v[20];
+                unpack4(t32(&T.y[8 + l][pb + 12]), v);
+                const uint4 w = t128(&T.y[8 + l][cb]);
+                unpack4(w.x, v + 4); unpack4(w.y, v + 8); unpack4(w.z, v + 12); unpack4(w.w, v + 16);
+                filter_line<20>(v, simple, x > 0, inner, level, ilevel, hlevel);
+                t32(&T.y[8 + l][pb + 12]) = pack4i(v);
+                t128(&T.y[8 + l][cb]) = make_uint4(pack4i(v + 4), pack4i(v + 8), pack4i(v + 12), pack4i(v + 16));
+            }
+            if (!simple) {
+                int v[12];
+                unpack4(t32(&T.c[lp][4 + lr][pb8 + 4]), v);
+                const uint2 w = t64(&T.c[lp][4 + lr][cb8]);
+                unpack4(w.x, v + 4); unpack4(w.y, v + 8);
+                filter_line<12>(v, false, x > 0, inner, level, ilevel, hlevel);
+                t32(&T.c[lp][4 + lr][pb8 + 4]) = pack4i(v);
+                t64(&T.c[lp][4 + lr][cb8]) = make_uint2(pack4i(v + 4), pack4i(v + 8));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        WP_PROF_MARK(2);
+        if (do_filter) {
+            // ---- 2b. horizontal edges: lane = pixel column; rows -4..15 relative to the MB ----
+            {
+                int v[20];
+#pragma unroll
+                for (int k = 0; k < 20; ++k) v[k] = T.y[4 + k][cb + l];
+                filter_line<20>(v, simple, y > 0, inner, level, ilevel, hlevel);
+#pragma unroll
+                for (int k = 1; k < 19; ++k) T.y[4 + k][cb + l] = uint8_t(v[k]);
+            }
+            if (!simple) {
+                int v[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) v[k] = T.c[lp][k][cb8 + lr];
+                filter_line<12>(v, false, y > 0, inner, level, ilevel, hlevel);
+#pragma unroll
+                for (int k = 1; k < 11; ++k) T.c[lp][k][cb8 + lr] = uint8_t(v[k]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        WP_PROF_MARK(3);
+        // ---- tell the band below how far this band's last row has got: the value of the PREVIOUS step,
+        //      whose stores were issued a whole step ago (the release fence then does not wait for acks) ----
+        settle(nx_y); settle(nx_ty); settle(nx_c); settle(nx_tc); settle(nx_fp);   // prefetch landed long ago; wait before the stores go out
+        if (has_below) {
+            if (pending_publish) publish_progress(&progress[wave], pending_publish);
+            const int done = s - 2 * (kBandRows - 1) + 1;
+            pending_publish = done >= 1 ? ((q << kSeqShift) | uint32_t(done)) : 0u;
+        }
+
+        WP_PROF_MARK(4);
+        if (act) {
+            // ---- 3. emit S tile (x, y): rows -8..7, cols -8..7 relative to the MB, all final ----
+            uint8_t* st = srow + size_t(x) * kTileBytes;
+            const uint2 a = t64(&T.y[l][pb + 8]), b = t64(&T.y[l][cb]);
+            st_nt(reinterpret_cast<uint4*>(st + 16 * l), make_uint4(a.x, a.y, b.x, b.y));
+            st_nt(reinterpret_cast<uint2*>(st + kTileCb + 8 * l), make_uint2(t32(&T.c[lp][lr][pb8 + 4]), t32(&T.c[lp][lr][cb8])));
+            if (x == mbw - 1) {        // right-most tile column: cols 8..15 (left half of tile mbw)
+                *reinterpret_cast<uint2*>(st + kTileBytes + 16 * l) = t64(&T.y[l][cb + 8]);
+                *reinterpret_cast<uint32_t*>(st + kTileBytes + kTileCb + 8 * l) = t32(&T.c[lp][lr][cb8 + 4]);
+            }
+            // ---- 4. hand the eight bottom rows (cols -8..7; state after this MB) down ----
+            const uint2 vy = t64(&T.y[16 + hr][hh ? cb : pb + 8]);
+            const uint32_t vc = t32(&T.c[lp][8 + hcr][hh ? cb8 : pb8 + 4]);
+            if (!last_row) {
+                t64(&lds.ring_y[g + 1][hr][(16 * x - 8 + 8 * hh) & 63]) = vy;
+                t32(&lds.ring_c[g + 1][lp][hcr][(8 * x - 4 + 4 * hh) & 31]) = vc;
+                if (x == mbw - 1 && hh) {   // cols 8..15 of the last MB
+                    t64(&lds.ring_y[g + 1][hr][(16 * x + 8) & 63]) = t64(&T.y[16 + hr][cb + 8]);
+                    t32(&lds.ring_c[g + 1][lp][hcr][(8 * x + 4) & 31]) = t32(&T.c[lp][8 + hcr][cb8 + 4]);
+                }
+            } else {
+                uint8_t* sn = st + size_t(spitch) * kTileBytes;       // S tile (x, y+1); tile row mbh exists
+                *reinterpret_cast<uint2*>(sn + 16 * hr + 8 * hh) = vy;
+                *reinterpret_cast<uint32_t*>(sn + kTileCb + 64 * lp + 8 * hcr + 4 * hh) = vc;
+                if (x == mbw - 1 && hh) {
+                    *reinterpret_cast<uint2*>(sn + kTileBytes + 16 * hr) = t64(&T.y[16 + hr][cb + 8]);
+                    *reinterpret_cast<uint32_t*>(sn + kTileBytes + kTileCb + 64 * lp + 8 * hcr) = t32(&T.c[lp][8 + hcr][cb8 + 4]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        WP_PROF_MARK(5);
+    }
+    if (has_below && pending_publish) publish_progress(&progress[wave], pending_publish);
+    WP_PROF_FLUSH(0);
+}
+
+}  // namespace wpk

@@ -65,7 +65,7 @@ __device__ __forceinline__ void st_nt(uint2* p, uint2 v) { const u32x2_t w = {v.
 // Optional per-phase cycle profile of the wavefront kernels (tuning builds only: -DWP_PROFILE).  Wave 0 of workgroup 0
 // accumulates s_memtime deltas per phase and adds them to wp_prof[] at the end of each band; tools read the symbol.
 #ifdef WP_PROFILE
-// (each profiled .hip file defines its own `static __device__ unsigned long long wp_prof[32]` before including kernels)
+static __device__ unsigned long long wp_prof[32];      // one copy per translation unit
 #define WP_PROF_DECL unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const bool prof_on = blockIdx.x == 0 && (threadIdx.x >> 6) == 0
 #define WP_PROF_MARK(i) do { if (prof_on) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); prof_acc[i] += now_ - prof_t; prof_t = now_; } } while (0)
 #define WP_PROF_FLUSH(base) do { if (prof_on && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&wp_prof[(base) + i_], prof_acc[i_]); } } while (0)
