@@ -111,11 +111,11 @@ __device__ __forceinline__ void filter_line(int (&v)[N], bool simple, bool mb_ed
     }
 }
 
-// One band.  `q` is the band's sequence number in this workgroup (band q-1 is the band above when band > 0), `progress`
+// One band.  `q` is the band's sequence number in this workgroup, `q_prev` that of the band above (band > 0), `progress`
 // the workgroup's LDS progress words (one per wavefront, W of them).  The caller has made sure that the band's R tiles
 // are complete and visible.
 template <int W>
-__device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, int n_bands, uint32_t q, int wave, uint32_t* progress,
+__device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, int n_bands, uint32_t q, uint32_t q_prev, int wave, uint32_t* progress,
                                             FilterWaveLds& lds, const uint32_t* __restrict__ filt, const uint8_t* __restrict__ Rp, uint8_t* Sp) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4;
@@ -135,7 +135,7 @@ __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, in
     const bool row_ok = y < mbh;
     const bool has_above = band > 0;
     const bool has_below = band + 1 < n_bands;
-    const int prev_wave = (wave + W - 1) % W;
+    const int prev_wave = int(q_prev % uint32_t(W));        // the wavefront that runs the band above
     const int rows_here = min(kBandRows, mbh - band * kBandRows);
     const int n_steps = mbw + 2 * (rows_here - 1);
     const bool last_row = g == rows_here - 1;             // its bottom rows leave the band through the S tiles
@@ -154,7 +154,7 @@ __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, in
     uint4 nx_y = make_uint4(0, 0, 0, 0);
     uint2 nx_c = make_uint2(0, 0), nx_ty = make_uint2(0, 0);
     uint32_t nx_fp = 0, nx_tc = 0;
-    if (has_above) wait_progress(&progress[prev_wave], ((q - 1) << kSeqShift) | uint32_t(min(2, mbw)));
+    if (has_above) wait_progress(&progress[prev_wave], (q_prev << kSeqShift) | uint32_t(min(2, mbw)));
     if (row_ok && g == 0) {
         nx_y = ld_nt(reinterpret_cast<const uint4*>(rrow + 16 * l));
         nx_c = ld_nt(reinterpret_cast<const uint2*>(rrow + kTileCb + 8 * l));
@@ -173,7 +173,7 @@ __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, in
         const uint2 cur_c = nx_c, cur_ty = nx_ty;
         const uint32_t fp = nx_fp, cur_tc = nx_tc;
         if (has_above && s + 1 < mbw)
-            wait_progress(&progress[prev_wave], ((q - 1) << kSeqShift) | uint32_t(min(s + 3, mbw)));
+            wait_progress(&progress[prev_wave], (q_prev << kSeqShift) | uint32_t(min(s + 3, mbw)));
         if (row_ok && x + 1 >= 0 && x + 1 < mbw) {
             const size_t o = size_t(x + 1) * kTileBytes;
             nx_y = ld_nt(reinterpret_cast<const uint4*>(rrow + o + 16 * l));

@@ -44,7 +44,7 @@ void vp8_recon_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, con
         for (int band = 0; band < n_bands; ++band) {
             const uint32_t q = seq + uint32_t(band);
             if (int(q % kReconWaves) != wave) continue;
-            recon_band<kReconWaves>(fr, band, n_bands, q, wave, progress, lds_all[wave], mb, coeff, Rp, false);
+            recon_band<kReconWaves>(fr, band, n_bands, q, q - 1, wave, progress, lds_all[wave], mb, coeff, Rp, false);
         }
         seq += uint32_t(n_bands);
     }

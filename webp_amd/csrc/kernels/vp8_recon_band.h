@@ -245,11 +245,11 @@ __device__ __forceinline__ int group_sum8(int v) {
     return v;
 }
 
-// One band.  `q` is the band's sequence number in this workgroup (band q-1 is the band above when band > 0), `progress`
+// One band.  `q` is the band's sequence number in this workgroup, `q_prev` that of the band above (band > 0), `progress`
 // the workgroup's LDS progress words (one per wavefront, W of them).  mark_done: also publish kBandDone when the band's
 // last store has been issued (the fused kernel's loop-filter bands wait for that).
 template <int W>
-__device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int n_bands, uint32_t q, int wave, uint32_t* progress,
+__device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int n_bands, uint32_t q, uint32_t q_prev, int wave, uint32_t* progress,
                                            ReconWaveLds& lds, const uint4* __restrict__ mb, const int16_t* __restrict__ coeff,
                                            uint8_t* Rp, bool mark_done) {
     const int lane = threadIdx.x & 63;
@@ -264,7 +264,7 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
     const bool row_ok = y < mbh;
     const bool has_above = band > 0;
     const bool has_below = band + 1 < n_bands;
-    const int prev_wave = (wave + W - 1) % W;
+    const int prev_wave = int(q_prev % uint32_t(W));        // the wavefront that runs the band above
     const int rows_here = min(kBandRows, mbh - band * kBandRows);
     const int n_steps = mbw + 2 * (rows_here - 1);
 
@@ -321,7 +321,7 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
         uint32_t top_a = 0, top_b = 0;
         const bool fetch_top = has_above && s < mbw && g == 0 && l < 8;
         if (has_above && s < mbw) {
-            wait_progress(&progress[prev_wave], ((q - 1) << kSeqShift) | uint32_t(min(s + 2, mbw)));
+            wait_progress(&progress[prev_wave], (q_prev << kSeqShift) | uint32_t(min(s + 2, mbw)));
             if (fetch_top) {
                 // last luma row / last Cb row / last Cr row of the tile of MB (s+1, y-1)
                 const uint8_t* src0 = R + size_t(y - 1) * mbw * kTileBytes
