@@ -14,36 +14,50 @@ namespace wp {
 namespace {
 
 // vp8/Partition.hx:7-113.  `eof` reproduces unexpectedEOF: a read past the end yields false.
+// Partition.hx (the boolean decoder).  Same arithmetic and the same end-of-data behaviour as the reference (a bit that
+// needs a byte past the end sets the EOF flag and reads as 0, leaving the state untouched), but with a 64-bit window:
+// bytes are shifted in up to seven at a time instead of one per refill, and the normalisation tables are extended to
+// 256 entries (shift 0 above 126) so the per-bit path has no second branch.  `v` holds `nb` not yet consumed bits,
+// right-aligned; the decoder's 8-bit window is v >> (nb - 8).
 struct BoolReader {
     const uint8_t* p = nullptr;
     const uint8_t* end = nullptr;
+    uint64_t v = 0;
     int32_t range_m1 = 254;
-    int32_t bits = 0;
-    int n_bits = 0;
+    int nb = 0;
     bool eof = false;
 
-    void open(const uint8_t* b, size_t n) { p = b; end = b + n; range_m1 = 254; bits = 0; n_bits = 0; eof = false; }
+    void open(const uint8_t* b, size_t n) { p = b; end = b + n; range_m1 = 254; v = 0; nb = 0; eof = false; }
+
+    struct Norm { uint8_t shift[256], range[256]; };
+    static const Norm& norm() {
+        static const Norm t = [] {
+            Norm n{};
+            for (int i = 0; i < 256; ++i) { n.shift[i] = i < 127 ? wpd_BoolShift[i] : 0; n.range[i] = i < 127 ? wpd_BoolRange[i] : uint8_t(i); }
+            return n;
+        }();
+        return t;
+    }
 
     inline bool bit(int prob) {
-        if (n_bits < 8) {
-            if (p >= end) { eof = true; return false; }
-            bits |= int32_t(*p++) << (8 - n_bits);
-            n_bits += 8;
+        if (nb < 8) {
+            while (nb <= 56 && p < end) { v = (v << 8) | *p++; nb += 8; }
+            if (nb < 8) { eof = true; return false; }
         }
-        const int32_t split = ((range_m1 * prob) >> 8) + 1;
-        const bool b = bits >= (split << 8);
-        if (b) { range_m1 -= split; bits -= split << 8; } else { range_m1 = split - 1; }
-        if (range_m1 < 127) {
-            const int sh = wpd_BoolShift[range_m1];
-            range_m1 = wpd_BoolRange[range_m1];
-            bits = int32_t(uint32_t(bits) << sh);
-            n_bits -= sh;
-        }
+        const uint32_t split = ((uint32_t(range_m1) * uint32_t(prob)) >> 8) + 1;
+        const int pos = nb - 8;
+        const bool b = (v >> pos) >= split;
+        if (b) { range_m1 -= int32_t(split); v -= uint64_t(split) << pos; } else { range_m1 = int32_t(split) - 1; }
+        const Norm& t = norm_;
+        nb -= t.shift[range_m1];
+        range_m1 = t.range[range_m1];
         return b;
     }
     inline int uint(int prob, int n) { int u = 0; for (int i = n - 1; i >= 0; --i) if (bit(prob)) u |= 1 << i; return u; }
     inline int sint(int prob, int n) { const int u = uint(prob, n); return bit(prob) ? -u : u; }
     inline int opt_int(int prob, int n) { return bit(prob) ? sint(prob, n) : 0; }
+
+    const Norm& norm_ = norm();
 };
 
 constexpr int kUniform = 128;
