@@ -16,9 +16,13 @@ namespace {
 // vp8/Partition.hx:7-113.  `eof` reproduces unexpectedEOF: a read past the end yields false.
 // Partition.hx (the boolean decoder).  Same arithmetic and the same end-of-data behaviour as the reference (a bit that
 // needs a byte past the end sets the EOF flag and reads as 0, leaving the state untouched), but with a 64-bit window:
-// bytes are shifted in up to seven at a time instead of one per refill, and the normalisation tables are extended to
+// bytes are shifted in up to five at a time instead of one per refill, and the normalisation tables are extended to
 // 256 entries (shift 0 above 126) so the per-bit path has no second branch.  `v` holds `nb` not yet consumed bits,
 // right-aligned; the decoder's 8-bit window is v >> (nb - 8).
+// One degenerate case needs care: a partition whose first byte is 0xFF starts with value == range, which no later
+// step repairs; every bit then reads 1 and the reference's 32-bit `bits` grows until it wraps.  The comparison below
+// is therefore made on the same 32-bit quantity (window << 8, wrapped, signed), and the refill stops at 48 bits so that
+// the 24 window bits the reference keeps always lie inside `v`.
 struct BoolReader {
     const uint8_t* p = nullptr;
     const uint8_t* end = nullptr;
@@ -41,12 +45,12 @@ struct BoolReader {
 
     inline bool bit(int prob) {
         if (nb < 8) {
-            while (nb <= 56 && p < end) { v = (v << 8) | *p++; nb += 8; }
+            while (nb <= 40 && p < end) { v = (v << 8) | *p++; nb += 8; }
             if (nb < 8) { eof = true; return false; }
         }
         const uint32_t split = ((uint32_t(range_m1) * uint32_t(prob)) >> 8) + 1;
         const int pos = nb - 8;
-        const bool b = (v >> pos) >= split;
+        const bool b = int32_t(uint32_t(v >> pos) << 8) >= int32_t(split << 8);
         if (b) { range_m1 -= int32_t(split); v -= uint64_t(split) << pos; } else { range_m1 = int32_t(split) - 1; }
         const Norm& t = norm_;
         nb -= t.shift[range_m1];
