@@ -69,3 +69,30 @@ def test_partition_starting_with_ff(name):
         for cut in (at + 1, at + 9, at + 200, len(m) // 2):
             n_ok += _agree(bytes(m[:cut]), "%s@%d cut %d" % (name, at, cut))
     assert n_ok > 0
+
+
+@pytest.mark.parametrize("name", ["1", "2", "4"])
+def test_mutated_streams_agree_with_oracle(name):
+    """Differential check of the host parser against the oracle's bitstream decode on damaged streams (byte flips in
+    the headers, in the partitions, truncation): the same streams are refused, and the accepted ones decode alike
+    (decodeFrame's null on unexpectedEOF, Q11, included)."""
+    d = np.frombuffer(golden_input(name), np.uint8)
+    rng = np.random.default_rng(sum(map(ord, name)))
+    n_ok = n_bad = 0
+    for it in range(36):
+        m = d.copy()
+        kind = it % 4
+        if kind == 0:
+            m = m[:rng.integers(20, m.size)]
+        elif kind == 1:
+            m[rng.integers(30, m.size, 3)] = rng.integers(0, 256, 3)
+        elif kind == 2:
+            m[rng.integers(20, 64, 2)] = rng.integers(0, 256, 2)
+        else:
+            p = int(rng.integers(30, m.size - 64))
+            m[p:p + 48] = rng.integers(0, 256, 48)
+        if _agree(m.tobytes(), "%s mutation %d" % (name, it)):
+            n_ok += 1
+        else:
+            n_bad += 1
+    assert n_ok > 0
