@@ -353,10 +353,24 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
             if (present || dc16 != 0) idct_residual(c, ev, od);
         }
         uint32_t cev[4] = {0, 0, 0, 0}, cod[4] = {0, 0, 0, 0};
-        if (act && chroma_lane && ((w2 >> cn) & 1)) {
-            int c[16];
-            unpack_block(cc0, cc1, c);
-            idct_residual(c, cev, cod);
+        {
+            // inverseDCT8 / inverseDCT8DCOnly (Vp8Decoder.hx:937-958): a block whose AC coefficients are all zero adds
+            // (dc + 4) >> 3 to every pixel, which is also what the full transform gives for it; the full transform
+            // is only run when some lane of the wavefront has a chroma block with AC (rare below ~q85).
+            const bool cpres = act && chroma_lane && ((w2 >> cn) & 1);
+            const bool c_ac = cpres && (((cc0.x >> 16) | cc0.y | cc0.z | cc0.w | cc1.x | cc1.y | cc1.z | cc1.w) != 0);
+            if (__builtin_amdgcn_ballot_w64(c_ac) != 0) {
+                if (cpres) {
+                    int c[16];
+                    unpack_block(cc0, cc1, c);
+                    idct_residual(c, cev, cod);
+                }
+            } else if (cpres) {
+                const int v = (int(int16_t(cc0.x & 0xffff)) + 4) >> 3;
+                const uint32_t p = as_u32(__builtin_amdgcn_cvt_pk_i16(v, v));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { cev[r] = p; cod[r] = p; }
+            }
         }
         WP_PROF_MARK(1);
         if (fetch_top) {
