@@ -33,14 +33,14 @@ int wpk_launch_alpha(int n, const wp_alpha_frame* frames_host, const wp_alpha_fr
 namespace {
 
 thread_local std::string g_error;
-int g_cus = 0;
+std::atomic<int> g_cus{0};      // compute units of the device (all devices of a node are the same part)
 
 int fail(int code, const std::string& msg) { g_error = msg; return code; }
 int hip_fail(hipError_t e, const char* what) { return fail(WP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hip_fail(e_, #expr); } while (0)
 
 int ensure_init() {
-    if (g_cus > 0) return WP_OK;
+    if (g_cus.load(std::memory_order_relaxed) > 0) return WP_OK;
     return wp_init(-1);
 }
 
@@ -96,7 +96,7 @@ int frames_per_launch(int n, const wp_vp8_frame* f) {
     long long max_bands = 1;
     for (int i = 0; i < n; ++i) max_bands = std::max(max_bands, (long long)(f[i].mbh + 3) / 4);
     const long long per_wg = std::max(1LL, (1LL << 19) / max_bands);
-    return int(std::min<long long>(n, per_wg * std::max(1, g_cus)));
+    return int(std::min<long long>(n, per_wg * std::max(1, g_cus.load(std::memory_order_relaxed))));
 }
 
 struct FinishGeom { int chunks = 1, rows = 1; };
@@ -146,7 +146,7 @@ int wp_init(int device) {
     HIP_TRY(hipGetDevice(&dev));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    g_cus = prop.multiProcessorCount;
+    g_cus.store(prop.multiProcessorCount, std::memory_order_relaxed);
     return WP_OK;
 }
 
@@ -183,7 +183,7 @@ int wp_vp8_recon_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, cons
     uint8_t* work = static_cast<uint8_t*>(d_work);
     const int per = frames_per_launch(n, fh);
     for (int first = 0; first < n; first += per) {
-        const int e = wpk_launch_vp8_recon(std::min(per, n - first), g_cus, fd + first, d_mb, d_coeff, work, hipStream_t(stream));
+        const int e = wpk_launch_vp8_recon(std::min(per, n - first), g_cus.load(std::memory_order_relaxed), fd + first, d_mb, d_coeff, work, hipStream_t(stream));
         if (e) return hip_fail(hipError_t(e), "vp8_recon launch");
     }
     if (planes) return launch_finish(n, fh, fd, work, w, 1, d_y, d_u, d_v, nullptr, nullptr, hipStream_t(stream));
@@ -213,7 +213,7 @@ int wp_vp8_loopfilter_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd,
     }
     const int per = frames_per_launch(n, fh);
     for (int first = 0; first < n; first += per) {
-        const int e = wpk_launch_vp8_filter(std::min(per, n - first), g_cus, fd + first, d_filt, work, work + w.r_bytes, hipStream_t(stream));
+        const int e = wpk_launch_vp8_filter(std::min(per, n - first), g_cus.load(std::memory_order_relaxed), fd + first, d_filt, work, work + w.r_bytes, hipStream_t(stream));
         if (e) return hip_fail(hipError_t(e), "vp8_filter launch");
     }
     if (planes) return launch_finish(n, fh, fd, work, w, 0, d_y, d_u, d_v, nullptr, nullptr, hipStream_t(stream));
@@ -252,7 +252,8 @@ int wp_yuv420_to_argb_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd,
     for (int first = 0; first < n; first += 65535) {
         const int cnt = std::min(65535, n - first);
         long long gx = (max_quads + 255) / 256;
-        const long long cap = std::max(1LL, (long long)g_cus * 32 / std::max(1, std::min(cnt, g_cus * 32)));
+        const int slots = g_cus.load(std::memory_order_relaxed) * 32;
+        const long long cap = std::max(1LL, (long long)slots / std::max(1, std::min(cnt, slots)));
         gx = std::min(gx, std::max(cap, 1LL) * 4);
         const int e = wpk_launch_yuv420_to_argb(cnt, int(gx), fd + first, d_y, d_u, d_v, d_alpha, d_argb, hipStream_t(stream));
         if (e) return hip_fail(hipError_t(e), "yuv420_to_argb launch");
@@ -367,7 +368,8 @@ int wp_vp8_decode_to_argb(int n, const wp_vp8_frame* frames, const uint32_t* mb,
         }
     }
     const Vp8Extents ex = vp8_extents(n, frames);
-    std::vector<wp_vp8_frame> planned(frames, frames + n);      // the caller's descriptors stay untouched
+    std::vector<wp_vp8_frame> planned;                          // the caller's descriptors stay untouched
+    try { planned.assign(frames, frames + n); } catch (const std::bad_alloc&) { return fail(WP_ERR_NOMEM, "out of memory"); }
     uint64_t work_bytes = 0;
     if ((rc = wp_vp8_plan(n, planned.data(), &work_bytes))) return rc;
     frames = planned.data();
@@ -472,10 +474,12 @@ int wp_parse(const uint8_t* data, size_t len, wp_parsed** out) {
     if (!p) return fail(WP_ERR_NOMEM, "out of memory");
     std::string err;
     int rc;
-    try {
+    try {                                   // no exception crosses the C ABI
         rc = wp::parse_webp(data, len, *p, err);
     } catch (const std::bad_alloc&) {
         rc = WP_ERR_NOMEM; err = "out of memory";
+    } catch (const std::exception& e) {
+        rc = WP_ERR_NOMEM; err = std::string("host parser: ") + e.what();
     }
     if (rc) { delete p; return fail(rc, err); }
     *out = p;
@@ -488,31 +492,44 @@ int wp_parse_batch(int n, const uint8_t* const* data, const size_t* len, int n_t
     if (n == 0) return WP_OK;
     if (n_threads <= 0) n_threads = int(std::max(1u, std::thread::hardware_concurrency()));
     n_threads = std::min(n_threads, n);
-    std::vector<int> st(static_cast<size_t>(n), WP_OK);
-    std::vector<std::string> msg(static_cast<size_t>(n));
+    for (int i = 0; i < n; ++i) out[i] = nullptr;
+    std::vector<int> st;
+    std::vector<std::string> msg;
+    try {
+        st.assign(static_cast<size_t>(n), WP_OK);
+        msg.resize(static_cast<size_t>(n));
+    } catch (const std::bad_alloc&) {
+        return fail(WP_ERR_NOMEM, "out of memory");
+    }
     std::atomic<int> next{0};
     auto worker = [&]() {
         for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
-            out[i] = nullptr;
             wp_parsed* p = new (std::nothrow) wp_parsed();
             if (!p) { st[size_t(i)] = WP_ERR_NOMEM; msg[size_t(i)] = "out of memory"; continue; }
             int rc;
             try {
                 rc = (!data[i] && len[i]) ? WP_ERR_INVALID : wp::parse_webp(data[i], len[i], *p, msg[size_t(i)]);
-            } catch (const std::bad_alloc&) {
-                rc = WP_ERR_NOMEM; msg[size_t(i)] = "out of memory";
+            } catch (const std::exception&) {     // bad_alloc and anything else the containers throw
+                rc = WP_ERR_NOMEM; msg[size_t(i)].clear();
             }
             if (rc) { delete p; st[size_t(i)] = rc; } else out[i] = p;
         }
     };
     std::vector<std::thread> pool;
-    for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    try {
+        for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    } catch (const std::exception&) {
+        // the system would not start another thread: the ones that run (and this one) share the work
+    }
     worker();
     for (auto& t : pool) t.join();
     int first = WP_OK;
     for (int i = n - 1; i >= 0; --i) {
         if (status) status[i] = st[size_t(i)];
-        if (st[size_t(i)]) { first = st[size_t(i)]; g_error = "file " + std::to_string(i) + ": " + msg[size_t(i)]; }
+        if (st[size_t(i)]) {
+            first = st[size_t(i)];
+            try { g_error = "file " + std::to_string(i) + ": " + (msg[size_t(i)].empty() ? std::string("out of memory") : msg[size_t(i)]); } catch (const std::exception&) {}
+        }
     }
     return first;
 }
