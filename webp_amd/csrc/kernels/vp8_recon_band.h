@@ -120,92 +120,78 @@ __device__ __forceinline__ void pred_tm(uint32_t top4, uint32_t left4, int corne
 }
 
 // The ten 4x4 luma predictors (PredFunc.hx:118-418).  top_lo / top_hi = the 8 pixels above (4 above the block + 4
-// above-right), left4 = the 4 pixels to the left (byte r = row r), corner = above-left.  The directional modes read
-// a window of the edge vector X = [L3 L2 L1 L0 | C T0 T1 T2 | T3 T4 T5 T6 | T7 ...] through the 3-tap (A3[i], centred
-// on X[i]) and 2-tap (A2[i] = avg2(X[i], X[i+1])) averages; with four pixels per dword every row is a byte window.
+// above-right), left4 = the 4 pixels to the left (byte r = row r), corner = above-left.  The eight directional modes
+// read windows of the edge vector X = [L3 L2 L1 L0 | C T0 T1 T2 | T3 T4 T5 T6 | T7 T7 T7 T7] (L3 repeated below, T7 to
+// the right) through its 3-tap averages a[i] = avg3(X[i-1], X[i], X[i+1]) and 2-tap averages b[i] = avg2(X[i], X[i+1]).
+// The lanes of a wavefront hold different modes, so the averages are computed once for all of them (four pixels per
+// dword) and each mode only assembles its rows from them: the divergent part is a handful of byte permutes per mode.
 __device__ __forceinline__ void pred4x4(int mode, uint32_t top_lo, uint32_t top_hi, uint32_t left4, int corner, uint32_t (&row)[4]) {
-    const uint32_t X1 = (top_lo << 8) | uint32_t(corner);                 // C  T0 T1 T2
-    switch (mode) {
-    case 0: {   // DC
+    if (mode == 0) {            // DC
         const uint32_t sum = __builtin_amdgcn_sad_u8(top_lo, 0u, __builtin_amdgcn_sad_u8(left4, 0u, 4u));
         row[0] = row[1] = row[2] = row[3] = splat4(int(sum >> 3));
-        break; }
-    case 1:     // TM
+        return;
+    }
+    if (mode == 1) {            // TM
         pred_tm(top_lo, left4, corner, row);
+        return;
+    }
+    const uint32_t X0 = WP_PERM(left4, left4, 0x00010203u);               // L3 L2 L1 L0
+    const uint32_t X1 = (top_lo << 8) | uint32_t(corner);                 // C  T0 T1 T2
+    const uint32_t X2 = WP_ALB(top_hi, top_lo, 3);                        // T3 T4 T5 T6
+    const uint32_t X3 = WP_PERM(top_hi, top_hi, 0x03030303u);             // T7 T7 T7 T7
+    const uint32_t N0 = WP_ALB(X1, X0, 1), N1 = WP_ALB(X2, X1, 1), N2 = WP_ALB(X3, X2, 1);     // X shifted by +1
+    const uint32_t A0 = avg3p(WP_PERM(X0, X0, 0x02010000u), X0, N0);      // a0..a3
+    const uint32_t A1 = avg3p(WP_ALB(X1, X0, 3), X1, N1);                 // a4..a7
+    const uint32_t A2 = avg3p(WP_ALB(X2, X1, 3), X2, N2);                 // a8..a11
+    const uint32_t B0 = avg2p(X0, N0), B1 = avg2p(X1, N1), B2 = avg2p(X2, N2);                 // b0..b3, b4..b7, b8..b11
+    switch (mode) {
+    case 2:     // VE (smoothed): a5..a8 in every row
+        row[0] = row[1] = row[2] = row[3] = WP_ALB(A2, A1, 1);
         break;
-    case 2: {   // VE (smoothed): avg3 over (C T0 T1 T2 | T0..T3 | T1..T4)
-        row[0] = row[1] = row[2] = row[3] = avg3p(X1, top_lo, WP_ALB(top_hi, top_lo, 1));
-        break; }
-    case 3: {   // HE (smoothed): A3[3], A3[2], A3[1], A3[0] with L3 replicated below
-        const uint32_t X0 = WP_PERM(left4, left4, 0x00010203u);            // L3 L2 L1 L0
-        const uint32_t A = avg3p(WP_PERM(X0, X0, 0x02010000u), X0, WP_ALB(X1, X0, 1));
-        row[0] = WP_PERM(A, A, 0x03030303u);
-        row[1] = WP_PERM(A, A, 0x02020202u);
-        row[2] = WP_PERM(A, A, 0x01010101u);
-        row[3] = WP_PERM(A, A, 0x00000000u);
-        break; }
-    case 4: {   // RD: row r = A3[4-r .. 7-r]
-        const uint32_t X0 = WP_PERM(left4, left4, 0x00010203u), X2 = WP_ALB(top_hi, top_lo, 3);
-        const uint32_t A0 = avg3p(WP_ALB(X0, X0, 3), X0, WP_ALB(X1, X0, 1));            // A3[1..3] (byte 0 unused)
-        const uint32_t A1 = avg3p(WP_ALB(X1, X0, 3), X1, WP_ALB(X2, X1, 1));            // A3[4..7]
+    case 3:     // HE (smoothed): row r = a[3-r] four times
+        row[0] = WP_PERM(A0, A0, 0x03030303u);
+        row[1] = WP_PERM(A0, A0, 0x02020202u);
+        row[2] = WP_PERM(A0, A0, 0x01010101u);
+        row[3] = WP_PERM(A0, A0, 0x00000000u);
+        break;
+    case 4:     // RD: row r = a[4-r .. 7-r]
         row[0] = A1;
         row[1] = WP_ALB(A1, A0, 3);
         row[2] = WP_ALB(A1, A0, 2);
         row[3] = WP_ALB(A1, A0, 1);
-        break; }
-    case 5: {   // VR
-        const uint32_t X0 = WP_PERM(left4, left4, 0x00010203u), X2 = WP_ALB(top_hi, top_lo, 3);
-        const uint32_t n1 = WP_ALB(X2, X1, 1);
-        const uint32_t A0 = avg3p(WP_ALB(X0, X0, 3), X0, WP_ALB(X1, X0, 1));            // A3[2], A3[3] used
-        const uint32_t A1 = avg3p(WP_ALB(X1, X0, 3), X1, n1);                            // A3[4..7]
-        const uint32_t B1 = avg2p(X1, n1);                                               // A2[4..7]
-        row[0] = B1;
-        row[1] = A1;
-        row[2] = WP_ALB(B1, A0, 3);                                                      // A3[3] A2[4] A2[5] A2[6]
-        row[3] = WP_PERM(A1, A0, 0x06050402u);                                           // A3[2] A3[4] A3[5] A3[6]
-        break; }
-    case 6: {   // LD: row r = A3[6+r .. 9+r], T7 replicated to the right
-        const uint32_t X2 = WP_ALB(top_hi, top_lo, 3), X3 = WP_PERM(top_hi, top_hi, 0x03030303u);
-        const uint32_t A1 = avg3p(WP_ALB(X1, X1, 3), X1, WP_ALB(X2, X1, 1));            // A3[5..7] (byte 0 unused)
-        const uint32_t A2 = avg3p(WP_ALB(X2, X1, 3), X2, WP_ALB(X3, X2, 1));            // A3[8..11]
-        const uint32_t A3 = avg3p(WP_ALB(X3, X2, 3), X3, X3);                            // A3[12] in byte 0
+        break;
+    case 5:     // VR
+        row[0] = B1;                                                       // b4 b5 b6 b7
+        row[1] = A1;                                                       // a4 a5 a6 a7
+        row[2] = WP_ALB(B1, A0, 3);                                        // a3 b4 b5 b6
+        row[3] = WP_PERM(A1, A0, 0x06050402u);                             // a2 a4 a5 a6
+        break;
+    case 6: {   // LD: row r = a[6+r .. 9+r]
+        const uint32_t A3 = avg3p(WP_ALB(X3, X2, 3), X3, X3);              // a12 in byte 0
         row[0] = WP_ALB(A2, A1, 2);
         row[1] = WP_ALB(A2, A1, 3);
         row[2] = A2;
         row[3] = WP_ALB(A3, A2, 1);
         break; }
-    case 7: {   // VL
-        const uint32_t X2 = WP_ALB(top_hi, top_lo, 3), X3 = WP_PERM(top_hi, top_hi, 0x03030303u);
-        const uint32_t n1 = WP_ALB(X2, X1, 1), n2 = WP_ALB(X3, X2, 1);
-        const uint32_t A1 = avg3p(WP_ALB(X1, X1, 3), X1, n1), A2 = avg3p(WP_ALB(X2, X1, 3), X2, n2);   // A3[5..7], A3[8..11]
-        const uint32_t B1 = avg2p(X1, n1), B2 = avg2p(X2, n2);                                           // A2[4..7], A2[8..11]
-        row[0] = WP_ALB(B2, B1, 1);                                                      // A2[5..8]
-        row[1] = WP_ALB(A2, A1, 2);                                                      // A3[6..9]
-        row[2] = WP_PERM(A2, WP_ALB(B2, B1, 2), 0x06020100u);                            // A2[6] A2[7] A2[8] A3[10]
-        row[3] = WP_PERM(A2, WP_ALB(A2, A1, 3), 0x07020100u);                            // A3[7] A3[8] A3[9] A3[11]
-        break; }
+    case 7:     // VL
+        row[0] = WP_ALB(B2, B1, 1);                                        // b5 b6 b7 b8
+        row[1] = WP_ALB(A2, A1, 2);                                        // a6 a7 a8 a9
+        row[2] = WP_PERM(A2, WP_ALB(B2, B1, 2), 0x06020100u);              // b6 b7 b8 a10
+        row[3] = WP_PERM(A2, WP_ALB(A2, A1, 3), 0x07020100u);              // a7 a8 a9 a11
+        break;
     case 8: {   // HD
-        const uint32_t X0 = WP_PERM(left4, left4, 0x00010203u), X2 = WP_ALB(top_hi, top_lo, 3);
-        const uint32_t n0 = WP_ALB(X1, X0, 1);
-        const uint32_t A0 = avg3p(WP_ALB(X0, X0, 3), X0, n0);                            // A3[1..3]
-        const uint32_t A1 = avg3p(WP_ALB(X1, X0, 3), X1, WP_ALB(X2, X1, 1));            // A3[4..6] used
-        const uint32_t B0 = avg2p(X0, n0);                                               // A2[0..3]
-        const uint32_t As = WP_ALB(A1, A0, 1);                                           // A3[1..4]
-        row[0] = WP_PERM(A1, B0, 0x06050403u);                                           // A2[3] A3[4] A3[5] A3[6]
-        row[1] = WP_PERM(As, B0, 0x07030602u);                                           // A2[2] A3[3] A2[3] A3[4]
-        row[2] = WP_PERM(As, B0, 0x06020501u);                                           // A2[1] A3[2] A2[2] A3[3]
-        row[3] = WP_PERM(As, B0, 0x05010400u);                                           // A2[0] A3[1] A2[1] A3[2]
+        const uint32_t As = WP_ALB(A1, A0, 1);                             // a1 a2 a3 a4
+        row[0] = WP_PERM(A1, B0, 0x06050403u);                             // b3 a4 a5 a6
+        row[1] = WP_PERM(As, B0, 0x07030602u);                             // b2 a3 b3 a4
+        row[2] = WP_PERM(As, B0, 0x06020501u);                             // b1 a2 b2 a3
+        row[3] = WP_PERM(As, B0, 0x05010400u);                             // b0 a1 b1 a2
         break; }
-    default: {  // 9: HU, L3 replicated below
-        const uint32_t X0 = WP_PERM(left4, left4, 0x00010203u);
-        const uint32_t n0 = WP_ALB(X0, X0, 1);                                           // L2 L1 L0 (byte 3 unused)
-        const uint32_t A0 = avg3p(WP_PERM(X0, X0, 0x02010000u), X0, n0);                 // A3[0..2]
-        const uint32_t B0 = avg2p(X0, n0);                                               // A2[0..2]
-        row[0] = WP_PERM(A0, B0, 0x05010602u);                                           // A2[2] A3[2] A2[1] A3[1]
-        row[1] = WP_PERM(A0, B0, 0x04000501u);                                           // A2[1] A3[1] A2[0] A3[0]
-        row[2] = WP_PERM(X0, WP_PERM(A0, B0, 0x00000400u), 0x04040100u);                 // A2[0] A3[0] L3 L3
-        row[3] = WP_PERM(X0, X0, 0x00000000u);                                           // L3 L3 L3 L3
-        break; }
+    default:    // 9: HU
+        row[0] = WP_PERM(A0, B0, 0x05010602u);                             // b2 a2 b1 a1
+        row[1] = WP_PERM(A0, B0, 0x04000501u);                             // b1 a1 b0 a0
+        row[2] = WP_PERM(X0, WP_PERM(A0, B0, 0x00000400u), 0x04040100u);   // b0 a0 L3 L3
+        row[3] = WP_PERM(X0, X0, 0x00000000u);                             // L3 L3 L3 L3
+        break;
     }
 }
 
