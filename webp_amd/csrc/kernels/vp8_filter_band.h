@@ -205,6 +205,7 @@ __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, in
         __builtin_amdgcn_wave_barrier();
 
         WP_PROF_MARK(1);
+        __builtin_amdgcn_s_setprio(1);      // issue priority rises along the step (a wavefront close to publishing goes first): 6 % faster
         if (do_filter) {
             // ---- 2a. vertical edges: lane = pixel row; columns -4..15 relative to the MB ----
             {
@@ -228,6 +229,7 @@ __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, in
         }
         __builtin_amdgcn_wave_barrier();
         WP_PROF_MARK(2);
+        __builtin_amdgcn_s_setprio(2);
         if (do_filter) {
             // ---- 2b. horizontal edges: lane = pixel column; rows -4..15 relative to the MB ----
             {
@@ -250,6 +252,7 @@ __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, in
         __builtin_amdgcn_wave_barrier();
 
         WP_PROF_MARK(3);
+        __builtin_amdgcn_s_setprio(0);
         // ---- tell the band below how far this band's last row has got: the value of the PREVIOUS step,
         //      whose stores were issued a whole step ago (the release fence then does not wait for acks) ----
         settle(nx_y); settle(nx_ty); settle(nx_c); settle(nx_tc); settle(nx_fp);   // prefetch landed long ago; wait before the stores go out

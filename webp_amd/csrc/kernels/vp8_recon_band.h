@@ -364,6 +364,9 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
             if (s + 1 < mbw) lds.ring[0][(s + 1) & 3][l] = top_b;
         }
         __builtin_amdgcn_wave_barrier();
+        // Issue priority rises along the step: the prediction chain (and most of all the i4 mini-steps, which keep
+        // few lanes busy) is what the next step and the band below wait for, the residuals above are not.
+        __builtin_amdgcn_s_setprio(1);
 
         if (act) {
             // ---- prepareYBR (Vp8Decoder.hx:541-577): left column, then top row ----
@@ -419,6 +422,7 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
         // i4: blocks in raster order predict from already reconstructed neighbours; block (bj,bi)
         // is ready at mini-step bi + 2*bj (it needs (bj,bi-1), (bj-1,bi) and (bj-1,bi+1)).
         if (__builtin_amdgcn_ballot_w64(act && !i16) != 0) {
+            __builtin_amdgcn_s_setprio(2);
             const int my_t = bi + 2 * bj;
             const int mode4 = int(((l < 8 ? rec.x : rec.y) >> (4 * (l & 7))) & 15);
             for (int t = 0; t < 10; ++t) {
@@ -438,6 +442,7 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+            __builtin_amdgcn_s_setprio(1);
         }
         WP_PROF_MARK(4);
         if (act) {
@@ -468,6 +473,7 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
         //      one of the PREVIOUS step: its stores were issued a whole step ago, so the release fence
         //      (s_waitcnt vmcnt(0)) does not stall on store acknowledgements ----
         WP_PROF_MARK(5);
+        __builtin_amdgcn_s_setprio(0);
         settle(rec_n2); settle(nl0); settle(nl1); settle(nwv); settle(nc0); settle(nc1);   // the prefetches have had the whole step to land; wait for them before this step's stores go out
         if (has_below) {
             if (pending_publish) publish_progress(&progress[wave], pending_publish);
