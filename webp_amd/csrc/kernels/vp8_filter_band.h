@@ -39,12 +39,17 @@ __device__ __forceinline__ int clamp255(int v) { return clampi(v, 0, 255); }
 // the sample arrays then stay in registers.  "Not filtered" is expressed as zero deltas, which
 // leaves the 0..255 samples unchanged through clamp255.
 
-// filter2, one position (Filter.hx:29-50): returns the deltas for p0 (added) and q0 (subtracted)
+// "Not filtered" is folded into the filter value itself: with a = 0 every delta below comes out 0 ((0 + 4) >> 3,
+// (0 + 3) >> 3, (0 + 1) >> 1 and (k * 0 + 63) >> 7 are all 0), so one select replaces one per delta.  absdiff() is
+// always called with its arguments in position order, so that the difference an edge shares with the next edge of the
+// line (its |q2 - q3| is the next one's |p1 - p0|) is computed once.
+
+// filter2, one position (Filter.hx:29-50)
 __device__ __forceinline__ void simple_edge(int p1, int& p0, int& q0, int q1, int level) {
     const bool on = (absdiff(p0, q0) << 1) + (absdiff(p1, q1) >> 1) <= level;
-    const int a = 3 * (q0 - p0) + clamp127(p1 - q1);
-    const int a1 = on ? clamp15((a + 4) >> 3) : 0;
-    const int a2 = on ? clamp15((a + 3) >> 3) : 0;
+    const int a = on ? 3 * (q0 - p0) + clamp127(p1 - q1) : 0;
+    const int a1 = clamp15((a + 4) >> 3);
+    const int a2 = clamp15((a + 3) >> 3);
     p0 = clamp255(p0 + a2);
     q0 = clamp255(q0 - a1);
 }
@@ -53,29 +58,29 @@ __device__ __forceinline__ void simple_edge(int p1, int& p0, int& q0, int q1, in
 template <bool FOUR>
 __device__ __forceinline__ void normal_edge(int p3, int& p2, int& p1, int& p0, int& q0, int& q1, int& q2, int q3,
                                             int level, int ilevel, int hlevel) {
-    const int d10 = absdiff(p1, p0), e10 = absdiff(q1, q0);
-    const int worst = max(max(max(absdiff(p3, p2), absdiff(p2, p1)), max(d10, e10)), max(absdiff(q2, q1), absdiff(q3, q2)));
+    const int m10 = max(absdiff(p1, p0), absdiff(q0, q1));
+    const int worst = max(max(max(absdiff(p3, p2), absdiff(p2, p1)), m10), max(absdiff(q1, q2), absdiff(q2, q3)));
     const bool on = (absdiff(p0, q0) << 1) + (absdiff(p1, q1) >> 1) <= level && worst <= ilevel;
-    const bool hev = d10 > hlevel || e10 > hlevel;
+    const bool hev = m10 > hlevel;
     const int base = 3 * (q0 - p0);
     const int outer = clamp127(p1 - q1);
     if (FOUR) {
-        const int a = base + (hev ? outer : 0);
-        const int a1 = on ? clamp15((a + 4) >> 3) : 0;
-        const int a2 = on ? clamp15((a + 3) >> 3) : 0;
-        const int a3 = hev ? 0 : (a1 + 1) >> 1;            // a1 == 0 when !on
+        const int a = on ? base + (hev ? outer : 0) : 0;
+        const int a1 = clamp15((a + 4) >> 3);
+        const int a2 = clamp15((a + 3) >> 3);
+        const int a3 = hev ? 0 : (a1 + 1) >> 1;
         p1 = clamp255(p1 + a3);
         p0 = clamp255(p0 + a2);
         q0 = clamp255(q0 - a1);
         q1 = clamp255(q1 - a3);
     } else {
-        const int w = base + outer;
+        const int w = on ? base + outer : 0;
         const int a = clamp127(w);
         const int c1 = (27 * a + 63) >> 7, c2 = (18 * a + 63) >> 7, c3 = (9 * a + 63) >> 7;
-        const int dp0 = on ? (hev ? clamp15((w + 3) >> 3) : c1) : 0;
-        const int dq0 = on ? (hev ? clamp15((w + 4) >> 3) : c1) : 0;
-        const int d1 = (on && !hev) ? c2 : 0;
-        const int d2 = (on && !hev) ? c3 : 0;
+        const int dp0 = hev ? clamp15((w + 3) >> 3) : c1;
+        const int dq0 = hev ? clamp15((w + 4) >> 3) : c1;
+        const int d1 = hev ? 0 : c2;
+        const int d2 = hev ? 0 : c3;
         p2 = clamp255(p2 + d2);
         p1 = clamp255(p1 + d1);
         p0 = clamp255(p0 + dp0);
