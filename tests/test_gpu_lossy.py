@@ -110,6 +110,38 @@ def test_staged_workspace_path_equals_fused(dev_batch):
         assert torch.equal(db.argb[d.argb_off:d.argb_off + 4 * d.width * d.height], ref[d.argb_off:d.argb_off + 4 * d.width * d.height]), n
 
 
+def test_pipelined_steps_equal_serial(dev_batch):
+    """LossyPipeline (finishing pass of one step on a second stream while the next step reconstructs) gives the same
+    bytes as the serial path, for the same batch resubmitted and for two batches alternating."""
+    import glob
+    import os
+    import torch
+    from conftest import ROOT
+    from webp_amd import parse
+    from webp_amd.decoder import LossyBatch
+    from webp_amd.device import DeviceLossyBatch, LossyPipeline
+    names, files, ora, db = dev_batch
+    paths = sorted(glob.glob(os.path.join(ROOT, "bench_data", "lossy1080_q*_[0-2].webp")))
+    assert paths
+    other = [parse(open(p, "rb").read()) for p in paths]
+    db2 = DeviceLossyBatch(LossyBatch([other[i % len(other)].frames[0] for i in range(24)]))
+    refs = []
+    for d in (db, db2):
+        d.decode_to_argb()
+        torch.cuda.synchronize()
+        refs.append([t.clone() for t in (d.argb, d.y, d.u, d.v)])
+        for t in (d.argb, d.y, d.u, d.v):
+            t.zero_()
+    pipe = LossyPipeline()
+    for k in range(7):
+        pipe.submit((db, db2)[k & 1] if k < 4 else db2)
+    pipe.drain()
+    torch.cuda.synchronize()
+    for d, ref in zip((db, db2), refs):
+        for got, exp, what in zip((d.argb, d.y, d.u, d.v), ref, ("argb", "y", "u", "v")):
+            assert torch.equal(got, exp), what
+
+
 def test_workspace_checks():
     """A workspace that is too small, or descriptors that were not planned, are refused before any launch."""
     import ctypes
