@@ -6,8 +6,8 @@ both the filtered YUV420 planes and ARGB) over a batch of synthetic encoded 1920
 / coefficient / filter buffers are already resident in HBM (the host entropy decode and the H2D copy happen once, before
 the timed region).  Successive steps are software-pipelined over two HIP streams (webp_amd.device.LossyPipeline): the
 memory-bound finishing pass of step k runs while the issue-bound reconstruction of step k+1 has started; every step
-does all of its work and the timed region ends with both streams drained.  `--serial` times the single-stream fused
-call (wp_vp8_decode_to_argb_dev) instead; its figure is also reported in `config.serial_ms_per_step`.
+does all of its work and the timed region ends with both streams drained.  `--serial` runs the steps on one stream
+instead (each kernel alone on the GPU); `--alone` adds the single-stream figure to the pipelined run's JSON line.
 Metric: decoded Mpix/s, counting visible pixels, whole job over all GPUs.
 
   python bench.py --gpus N --steps K --warmup W [--images 1024]
@@ -68,7 +68,8 @@ def main():
                     "workgroup gives every wavefront the same number of bands and is ~10 %% faster per image)")
     ap.add_argument("--pattern", default="lossy1080_*.webp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--serial", action="store_true", help="one stream, one fused call per step (no overlap between steps)")
+    ap.add_argument("--serial", action="store_true", help="one stream per step, no overlap between steps (kernel times as when each runs alone)")
+    ap.add_argument("--alone", action="store_true", help="after the timed region also time the single-stream fused call (config.serial_ms_per_step)")
     args = ap.parse_args()
 
     import torch
@@ -96,19 +97,25 @@ def main():
     from webp_amd.device import LossyPipeline
     pipe = None if args.serial else LossyPipeline(device)
 
-    def run(n_steps):
-        if pipe is None:
-            for _ in range(n_steps):
+    marks = []                                       # per step: timing events around each kernel, on its launch stream
+
+    def run(n_steps, timing=None):
+        for _ in range(n_steps):
+            if pipe is not None:
+                pipe.submit(db, timing=timing)
+            elif timing is None:
                 db.decode_to_argb()
-        else:
-            for _ in range(n_steps):
-                pipe.submit(db)
+            else:                                    # the fused call's three launches, staged so that events fit between them
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                ev[0].record(); db.recon(planes=False); ev[1].record(); db.loopfilter(planes=False); ev[2].record(); db.finish(); ev[3].record()
+                timing.append((ev[0], ev[1], ev[1], ev[2], ev[2], ev[3]))
+        if pipe is not None:
             pipe.drain()
 
     run(max(args.warmup, 1) if pipe is not None else args.warmup)      # the streams' first use is slow: never time it
     barrier()
     t0 = time.perf_counter()
-    run(args.steps)
+    run(args.steps, marks)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -118,24 +125,22 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * px_per_step * args.steps / elapsed / 1e6
 
-    # ---- the same steps on one stream (no overlap), for reference ----
-    db.decode_to_argb(); torch.cuda.synchronize()
-    ts0 = time.perf_counter()
-    for _ in range(args.steps):
-        db.decode_to_argb()
-    torch.cuda.synchronize()
-    serial_ms = 1e3 * (time.perf_counter() - ts0) / args.steps
-
-    # ---- per-kernel timing (HIP events on the launch stream) and roofline of the dominant kernel ----
-    iters = max(3, min(args.steps, 10))
+    # ---- per-kernel launch durations over the timed region (HIP events on each kernel's launch stream) and the roofline
+    #      of the dominant kernel.  In the pipelined run a reconstruction shares the GPU with the previous step's
+    #      finishing pass, so its duration here is longer than when it runs alone (`--serial`, profiles/*serial*). ----
     acc = [0.0, 0.0, 0.0]
-    for _ in range(iters):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        ev[0].record(); db.recon(planes=False); ev[1].record(); db.loopfilter(planes=False); ev[2].record(); db.finish(); ev[3].record()
-        ev[3].synchronize()
+    for m in marks:
         for k in range(3):
-            acc[k] += ev[k].elapsed_time(ev[k + 1])
-    t_recon, t_filter, t_conv = (a / iters for a in acc)
+            acc[k] += m[2 * k].elapsed_time(m[2 * k + 1])
+    t_recon, t_filter, t_conv = (a / len(marks) for a in acc)
+    serial_ms = None
+    if args.alone and pipe is not None:              # the same steps on one stream (no overlap), for reference
+        db.decode_to_argb(); torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        for _ in range(args.steps):
+            db.decode_to_argb()
+        torch.cuda.synchronize()
+        serial_ms = 1e3 * (time.perf_counter() - ts0) / args.steps
     in_bytes = batch.input_bytes()
     yuv_bytes = 384 * n_mb
     argb_bytes = 4 * px_per_step
@@ -183,7 +188,7 @@ def main():
                        "host_parse_ms_per_image": round(1e3 * t_parse, 2),
                        "step_pipelining": "none (--serial)" if pipe is None else
                                           "2 HIP streams: finishing pass of step k overlaps reconstruction of step k+1",
-                       "serial_ms_per_step": round(serial_ms, 4)},
+                       "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 4)},
             "roofline": roofline}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(paths)

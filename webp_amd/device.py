@@ -36,6 +36,7 @@ class DeviceLossyBatch:
         self.v = torch.empty(max(batch.v_bytes, 16), dtype=torch.uint8, device=self.device)
         self.argb = torch.empty(max(batch.argb_bytes, 16), dtype=torch.uint8, device=self.device)
         self.alpha = _dev(alpha, self.device) if alpha is not None else None
+        self.has_unfiltered = any(batch.desc[i].filter_type == 0 for i in range(batch.n))   # read from the R tiles by the finishing pass
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -108,25 +109,41 @@ class LossyPipeline:
         self.s_main.wait_stream(cur)
         self.s_finish.wait_stream(cur)
 
-    def submit(self, db: "DeviceLossyBatch", planes=True, argb=True):
+    def submit(self, db: "DeviceLossyBatch", planes=True, argb=True, timing=None):
+        """Enqueues one step.  `timing`: a list that receives (recon start, recon end, filter start, filter end, finish
+        start, finish end) timing events recorded on the stream each kernel is launched on."""
+        def mark(stream):
+            if timing is None:
+                return None
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            return e
         while len(self._queued) >= self.max_in_flight:
             self._queued.pop(0).synchronize()
         fin = self._last_finish.get(id(db))
-        unfiltered = any(db.b.desc[i].filter_type == 0 for i in range(db.b.n))
+        unfiltered = db.has_unfiltered
         with torch.cuda.stream(self.s_main):
             if fin is not None and unfiltered:
                 self.s_main.wait_event(fin)
+            r0 = mark(self.s_main)
             db.recon(planes=False)
+            r1 = mark(self.s_main)
             if fin is not None and not unfiltered:
                 self.s_main.wait_event(fin)
+            f0 = mark(self.s_main)
             db.loopfilter(planes=False)
+            f1 = mark(self.s_main)
             filtered = torch.cuda.Event()
             filtered.record(self.s_main)
         with torch.cuda.stream(self.s_finish):
             self.s_finish.wait_event(filtered)
+            c0 = mark(self.s_finish)
             db.finish(planes, argb)
+            c1 = mark(self.s_finish)
             done = torch.cuda.Event()
             done.record(self.s_finish)
+        if timing is not None:
+            timing.append((r0, r1, f0, f1, c0, c1))
         self._last_finish[id(db)] = done
         self._queued.append(done)
         return done
