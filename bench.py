@@ -181,8 +181,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32/u8",
             "data": "synthetic",
-            "config": {"workload": "%d x 1920x1080 VP8 lossy (libwebp: 8 x q75 m4 normal filter + q90 + q50 sharp3 + simple-filter variant) per GPU: recon + loop filter + "
-                                   "finishing pass (YUV420 planes + ARGB out), inputs resident in HBM" % args.images,
+            "config": {"workload": "%d x %dx%d VP8 lossy (%s) per GPU: recon + loop filter + finishing pass (YUV420 planes + ARGB out), inputs resident in HBM"
+                                   % (args.images, batch.desc[0].width, batch.desc[0].height,
+                                      "libwebp: 8 x q75 m4 normal filter + q90 + q50 sharp3 + simple-filter variant" if args.pattern == "lossy1080_*.webp"
+                                      else "bench_data/" + args.pattern),
                        "images_per_gpu": args.images, "distinct_streams": len(paths), "sharding": "images across ranks, no collective",
                        "macroblocks_per_gpu": n_mb, "coeff_blocks_per_mb": round(batch.n_coeff_blocks / max(n_mb, 1), 3),
                        "host_parse_ms_per_image": round(1e3 * t_parse, 2),

@@ -69,7 +69,7 @@ def test_decode_to_argb_matches_golden(dev_batch):
             exp = golden_expected(n)[0].reshape(-1)
             _cmp(n, "ARGB vs reference golden", got, exp, 4 * ora[i]["width"])
         else:
-            # a.webp has no golden; alpha is handled in test_gpu_alpha.py, here the frame is converted opaque
+            # a.webp has no golden; alpha is handled in test_gpu_api.py and test_gpu_vp8l.py, here the frame is converted opaque
             rgb_exp = ora[i]["to_argb"].reshape(-1, 4)[:, 1:]
             assert np.array_equal(got.reshape(-1, 4)[:, 1:], rgb_exp)
 
