@@ -122,3 +122,27 @@ def test_out_of_range_block_index_is_refused():
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     with pytest.raises(WebPError, match="coefficient block index out of range in frame 0, macroblock 5"):
         check(lib().wp_vp8_decode_to_argb(1, desc, p(mb), 6, p(filt), p(coeff), coeff.size // 16, p(y), p(u), p(v), None, None))
+
+
+@pytest.mark.parametrize("shape", [(1024, 5), (3, 1024), (1024, 1)])
+def test_maximum_dimensions(shape):
+    """The largest macroblock grid a VP8 frame header can describe in one direction (14-bit dimensions: 16383 px = 1024
+    MBs): band progress words, tile indices and the finishing pass's row segments at their limits."""
+    from oracle import oracle
+    from webp_amd._lib import Vp8Frame, check, lib
+    w, h = shape
+    rng = np.random.default_rng(77 + w + 3 * h)
+    mb, coeff, filt = make_frame(rng, w, h, False)
+    desc = (Vp8Frame * 1)()
+    d = desc[0]
+    d.width, d.height, d.mbw, d.mbh, d.filter_type = min(16 * w, 16383), min(16 * h, 16383), w, h, 2
+    nmb = w * h
+    y = np.zeros(256 * nmb, np.uint8); u = np.zeros(64 * nmb, np.uint8); v = np.zeros(64 * nmb, np.uint8)
+    argb = np.zeros(4 * d.width * d.height, np.uint8)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    check(lib().wp_vp8_decode_to_argb(1, desc, p(mb), nmb, p(filt), p(coeff), coeff.size // 16, p(y), p(u), p(v), None, p(argb)))
+    exp = oracle.vp8_from_packed(w, h, mb, coeff, filt, 2)
+    for name, got in (("y", y), ("u", u), ("v", v)):
+        assert np.array_equal(got, exp[name]), "plane %s of a %d x %d MB frame" % (name, w, h)
+    want = oracle.yuv420_to_argb(exp["y"], 16 * w, exp["u"], exp["v"], 8 * w, None, d.width, d.height)
+    assert np.array_equal(argb, want)

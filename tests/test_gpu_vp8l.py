@@ -143,3 +143,17 @@ def test_alpha_unfilter_modes(rgba):
     for i, (w, h, f) in enumerate(items):
         got = out[desc[i].dst_off:desc[i].dst_off + w * h]
         assert np.array_equal(got, want[i]), (w, h, f)
+
+
+@pytest.mark.parametrize("shape", [(16384, 3), (3, 16384), (16384, 70)])
+def test_predictor_maximum_dimensions(shape):
+    """VP8L's largest width / height (14 bits + 1): the predictor's progress word holds a pixel count below 2^15, and a
+    16384-row image crosses 256 row bands."""
+    from oracle import oracle
+    w, h = shape
+    rng = np.random.default_rng(w + 7 * h)
+    bits = 4
+    pix = rng.integers(0, 256, 4 * w * h, dtype=np.uint8)
+    t = _tiles(rng, w, h, bits, list(range(14)))
+    got = _run_chain([dict(width=w, height=h, coded_width=w, pix=pix, transforms=[(0, bits, w, t)])])[0]
+    assert np.array_equal(got, oracle.inverse_predictor(w, bits, t, pix, h))
