@@ -215,6 +215,22 @@ void wp_parsed_free(wp_parsed* p);
  * throughput long before the kernels do).  out[i] receives the parsed object or NULL, status[i] its wp_status;
  * returns 0 if every file parsed, else the first failing status (wp_last_error holds that file's message). */
 int wp_parse_batch(int n, const uint8_t* const* data, const size_t* len, int n_threads, wp_parsed** out, int* status);
+/* Batch assembly for the lossy path: what `reconstruct`'s prologue and the per-MB capture of the filter parameters
+ * leave behind for one frame (Vp8Decoder.hx:772-808, 348-353), laid side by side for n frames so that one
+ * device call handles them.  files[i] / frame_index[i] (NULL = frame 0 everywhere) name lossy frames of parsed files.
+ * wp_vp8_batch_layout fills frames[i] (sizes, filter type, has_alpha = with_alpha[i] (NULL = none), mb_base / coeff_base
+ * and output offsets rounded up to 256 bytes, in the order given; stile_base as wp_vp8_plan would) and reports the slab
+ * sizes; wp_vp8_batch_gather then copies the records into the caller's slabs (host memory, pinned if they are to be
+ * uploaded asynchronously; capacities in MB records / coefficient blocks are checked) on up to n_threads threads. */
+typedef struct wp_vp8_batch_sizes {
+    uint64_t n_mb, n_coeff_blocks;                  /* MB / filter records, coefficient blocks (32 bytes each) */
+    uint64_t y_bytes, u_bytes, v_bytes, argb_bytes, alpha_bytes, work_bytes;
+} wp_vp8_batch_sizes;
+int wp_vp8_batch_layout(int n, const wp_parsed* const* files, const int* frame_index, const int* with_alpha,
+                        wp_vp8_frame* frames, wp_vp8_batch_sizes* sizes);
+int wp_vp8_batch_gather(int n, const wp_parsed* const* files, const int* frame_index, const wp_vp8_frame* frames,
+                        uint32_t* mb, uint32_t* filt, size_t n_mb_capacity, int16_t* coeff, size_t n_coeff_blocks_capacity,
+                        int n_threads);
 /* kind: 0 Yuv420, 1 Argb, 2 Anim (Image.hx:36-46) */
 int wp_parsed_kind(const wp_parsed* p);
 int wp_parsed_width(const wp_parsed* p);

@@ -177,3 +177,45 @@ def test_mutated_files_are_rejected_or_parsed_without_crashing():
                 assert rc < 0 and not h.value
                 n_bad += 1
     assert n_ok > 0 and n_bad > 0
+
+
+def test_batch_layout_and_gather():
+    """wp_vp8_batch_layout / wp_vp8_batch_gather: descriptors, bases and slabs equal the per-frame buffers laid end to end;
+    capacities and non-lossy items are checked."""
+    import ctypes as C
+    from webp_amd import parse
+    from webp_amd._lib import Vp8BatchSizes, Vp8Frame, WebPError, check, lib
+    from webp_amd.decoder import LossyBatch
+    files = [parse(golden_input(n)) for n in ("1", "3", "a", "2")]
+    frames = [f.frames[0] for f in files]
+    for threads in (1, 3):
+        b = LossyBatch(frames, threads=threads)
+        mb = np.concatenate([f.buf(0, np.uint32) for f in frames])
+        fl = np.concatenate([f.buf(1, np.uint32) for f in frames])
+        co = np.concatenate([f.buf(2, np.int16) for f in frames])
+        assert np.array_equal(b.mb, mb) and np.array_equal(b.filt, fl) and np.array_equal(b.coeff, co)
+        nmb = st = blocks = 0
+        for i, f in enumerate(frames):
+            d = b.desc[i]
+            assert (d.width, d.height, d.mbw, d.mbh, d.filter_type) == (f.width, f.height, f.mbw, f.mbh, f.filter_type)
+            assert (d.mb_base, d.stile_base, d.coeff_base) == (nmb, st, blocks)
+            assert d.y_off % 256 == 0 and d.u_off % 256 == 0 and d.argb_off % 256 == 0
+            nmb += f.mbw * f.mbh
+            st += (f.mbw + 1) * (f.mbh + 1)
+            blocks += f.buf(2, np.int16).size // 16
+        assert b.n_mb == nmb and b.n_coeff_blocks == blocks
+        assert b.work_bytes == (nmb * 384 + 255) // 256 * 256 + st * 384
+    L = lib()
+    n = len(frames)
+    hs = (C.c_void_p * n)(*[f._owner._h for f in frames])
+    desc = (Vp8Frame * n)()
+    sizes = Vp8BatchSizes()
+    check(L.wp_vp8_batch_layout(n, hs, None, None, desc, C.byref(sizes)))
+    small = np.zeros(16, np.uint32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    with pytest.raises(WebPError, match="slab too small"):
+        check(L.wp_vp8_batch_gather(n, hs, None, desc, p(small), p(small), 4, p(small), 1, 1))
+    lossless = parse(golden_input("1ll"))
+    hs2 = (C.c_void_p * 1)(lossless._h)
+    with pytest.raises(WebPError, match="not a lossy frame"):
+        check(L.wp_vp8_batch_layout(1, hs2, None, None, desc, C.byref(sizes)))

@@ -105,3 +105,30 @@ def test_corrupted_token_data_decodes_like_the_oracle(name):
                 assert np.array_equal(got[0], exp), "iteration %d" % it
                 checked += 1
     assert checked > 0
+
+
+def test_streaming_decode_equals_per_file_decode():
+    """webp_amd.streaming.LossyStream (chunked: threaded parse | pinned gather + H2D | kernels | D2H) returns for every
+    file what the one-file path returns, across chunk boundaries and mixed sizes."""
+    import glob
+    import os
+    import torch
+    from conftest import ROOT
+    from webp_amd import WebPDecoder, Tools
+    from webp_amd.streaming import LossyStream
+    paths = sorted(glob.glob(os.path.join(ROOT, "bench_data", "lossy_*.webp"))) + \
+        sorted(glob.glob(os.path.join(ROOT, "bench_data", "lossy1080_q*_[0-1].webp"))) + \
+        [os.path.join(ROOT, "tests", "golden", "inputs", n + ".webp") for n in ("1", "2", "3")]
+    datas = [open(p, "rb").read() for p in paths] * 2
+    argb, items, y, u, v = LossyStream(threads=4, chunk=5).decode(datas)
+    torch.cuda.synchronize()
+    assert len(items) == len(datas)
+    for i in (0, 1, 2, 4, 5, 6, len(datas) // 2, len(datas) - 1):
+        img = WebPDecoder.decode(datas[i])
+        it = items[i]
+        yy, uu, vv = img.data.y, img.data.u, img.data.v
+        assert np.array_equal(y[it["y_off"]:it["y_off"] + yy.size].numpy(), np.asarray(yy).reshape(-1)), paths[i % len(paths)]
+        assert np.array_equal(u[it["u_off"]:it["u_off"] + uu.size].numpy(), np.asarray(uu).reshape(-1))
+        assert np.array_equal(v[it["v_off"]:it["v_off"] + vv.size].numpy(), np.asarray(vv).reshape(-1))
+        want = np.asarray(Tools.toArgb(img).data.pix).reshape(-1)
+        assert np.array_equal(argb[it["argb_off"]:it["argb_off"] + want.size].numpy(), want), paths[i % len(paths)]

@@ -1,6 +1,8 @@
-"""End-to-end throughput (file bytes in host memory -> ARGB + planes in host memory) for batched 1080p lossy WebP:
-threaded host parse (wp_parse_batch), batch assembly, H2D, device pipeline, D2H.  Reported separately from bench.py,
-whose `value` is the device-resident rate.   python tools/e2e_bench.py [images] [threads]"""
+"""End-to-end throughput (file bytes in host memory -> ARGB + planes in pinned host memory) for batched 1080p lossy WebP.
+Reported separately from bench.py, whose `value` is the device-resident rate.
+  staged   : threaded host parse (wp_parse_batch) of everything, batch assembly, H2D, device pipeline, D2H, one after the other
+  streamed : webp_amd.streaming.LossyStream -- the same stages overlapped over chunks of files
+python tools/e2e_bench.py [images] [threads] [chunk]"""
 import glob, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,9 +10,11 @@ import torch
 from webp_amd import parse_many
 from webp_amd.decoder import LossyBatch
 from webp_amd.device import DeviceLossyBatch
+from webp_amd.streaming import LossyStream
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench_data", "lossy1080_*.webp")))
 datas = [open(paths[i % len(paths)], "rb").read() for i in range(n)]
 torch.cuda.init(); torch.zeros(1, device="cuda:0")
@@ -24,11 +28,11 @@ def to_host(name, t):
     pinned[name][:t.numel()].copy_(t, non_blocking=True)
 
 
-for rep in range(3):
+for rep in range(2):
     t0 = time.perf_counter()
     files = parse_many(datas, threads)
     t1 = time.perf_counter()
-    batch = LossyBatch([f.frames[0] for f in files])
+    batch = LossyBatch([f.frames[0] for f in files], threads=threads)
     t2 = time.perf_counter()
     db = DeviceLossyBatch(batch, "cuda:0")
     torch.cuda.synchronize()
@@ -40,6 +44,19 @@ for rep in range(3):
     torch.cuda.synchronize()
     t5 = time.perf_counter()
     px = sum(batch.desc[i].width * batch.desc[i].height for i in range(batch.n))
-    print("rep %d: %d images, %d threads: parse %.3f s (%.2f ms/image/thread), assemble %.3f, alloc+H2D %.3f, device %.4f, D2H %.3f  => %.1f Mpix/s end to end (parse only: %.1f Mpix/s)"
-          % (rep, n, threads, t1 - t0, 1e3 * (t1 - t0) * threads / n, t2 - t1, t3 - t2, t4 - t3, t5 - t4, px / (t5 - t0) / 1e6, px / (t1 - t0) / 1e6))
+    print("staged rep %d: %d images, %d threads: parse %.3f s (%.2f ms/image/thread), assemble %.3f, alloc+H2D %.3f, device %.4f, D2H %.3f  => %.1f Mpix/s end to end (parse only: %.1f Mpix/s)"
+          % (rep, n, threads, t1 - t0, 1e3 * (t1 - t0) * threads / n, t2 - t1, t3 - t2, t4 - t3, t5 - t4, px / (t5 - t0) / 1e6, px / (t1 - t0) / 1e6), flush=True)
     del db, files, batch
+pinned.clear()
+torch.cuda.empty_cache()
+
+stream = LossyStream("cuda:0", threads=threads, chunk=chunk, planes=True)
+for rep in range(3):
+    t0 = time.perf_counter()
+    out = stream.decode(datas)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("streamed rep %d: %d images, %d threads, chunks of %d: %.3f s => %.1f Mpix/s end to end" % (rep, n, threads, chunk, dt, px / dt / 1e6), flush=True)
+    chk = int(out[0][::40009].to(torch.int64).sum())
+    del out
+print("checksum", chk)

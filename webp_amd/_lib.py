@@ -34,6 +34,11 @@ class AlphaFrame(ctypes.Structure):        # wp_alpha_frame
                 ("src_is_vp8l_rgba", ctypes.c_int32), ("src_off", ctypes.c_uint64), ("dst_off", ctypes.c_uint64)]
 
 
+class Vp8BatchSizes(ctypes.Structure):   # wp_vp8_batch_sizes
+    _fields_ = [(k, ctypes.c_uint64) for k in ("n_mb", "n_coeff_blocks", "y_bytes", "u_bytes", "v_bytes", "argb_bytes",
+                                               "alpha_bytes", "work_bytes")]
+
+
 class WebPError(Exception):
     """Raised with the message the reference would `throw` (plus the native status code)."""
     def __init__(self, code, msg):
@@ -79,6 +84,8 @@ def lib():
     L.wp_parsed_free.argtypes = [vp]
     L.wp_parse_batch.argtypes = [i32, vp, vp, i32, vp, vp]
     L.wp_parsed_free.restype = None
+    L.wp_vp8_batch_layout.argtypes = [i32, vp, vp, vp, vp, ctypes.POINTER(Vp8BatchSizes)]
+    L.wp_vp8_batch_gather.argtypes = [i32, vp, vp, vp, vp, vp, sz, vp, sz, i32]
     for f in ("wp_parsed_kind", "wp_parsed_width", "wp_parsed_height", "wp_parsed_nframes"):
         getattr(L, f).argtypes = [vp]
     L.wp_parsed_frame_info.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_int32)]

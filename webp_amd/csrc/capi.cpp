@@ -533,6 +533,85 @@ int wp_parse_batch(int n, const uint8_t* const* data, const size_t* len, int n_t
     }
     return first;
 }
+namespace {
+const wp::ParsedFrame* lossy_frame(const wp_parsed* const* files, const int* frame_index, int i) {
+    const wp_parsed* p = files[i];
+    const int k = frame_index ? frame_index[i] : 0;
+    if (!p || k < 0 || size_t(k) >= p->frames.size() || p->frames[size_t(k)].type != 0) return nullptr;
+    return &p->frames[size_t(k)];
+}
+}  // namespace
+
+int wp_vp8_batch_layout(int n, const wp_parsed* const* files, const int* frame_index, const int* with_alpha,
+                        wp_vp8_frame* frames, wp_vp8_batch_sizes* sizes) {
+    if (n < 0 || (n > 0 && (!files || !frames)) || !sizes) return fail(WP_ERR_INVALID, "bad argument");
+    wp_vp8_batch_sizes z = {};
+    uint64_t st = 0;
+    for (int i = 0; i < n; ++i) {
+        const wp::ParsedFrame* f = lossy_frame(files, frame_index, i);
+        if (!f) return fail(WP_ERR_INVALID, "item " + std::to_string(i) + " is not a lossy frame of a parsed file");
+        const uint64_t nmb = uint64_t(f->vp8.mbw) * uint64_t(f->vp8.mbh);
+        if (z.n_mb + nmb > 0xffffffffull || st > 0xffffffffull) return fail(WP_ERR_INVALID, "batch too large for 32-bit record indices");
+        wp_vp8_frame& d = frames[i];
+        d = wp_vp8_frame{};
+        d.width = f->width; d.height = f->height; d.mbw = f->vp8.mbw; d.mbh = f->vp8.mbh;
+        d.filter_type = f->vp8.filter_type;
+        d.has_alpha = (with_alpha && with_alpha[i]) ? 1 : 0;
+        d.mb_base = uint32_t(z.n_mb); d.stile_base = uint32_t(st); d.coeff_base = z.n_coeff_blocks;
+        d.y_off = z.y_bytes; d.u_off = z.u_bytes; d.v_off = z.v_bytes; d.argb_off = z.argb_bytes; d.alpha_off = z.alpha_bytes;
+        z.n_mb += nmb;
+        st += uint64_t(d.mbw + 1) * uint64_t(d.mbh + 1);
+        z.n_coeff_blocks += f->vp8.coeff.size() / 16;
+        z.y_bytes += align_up(size_t(256 * nmb), 256);
+        z.u_bytes += align_up(size_t(64 * nmb), 256);
+        z.v_bytes += align_up(size_t(64 * nmb), 256);
+        z.argb_bytes += align_up(size_t(4) * size_t(d.width) * size_t(d.height), 256);
+        if (d.has_alpha) z.alpha_bytes += align_up(size_t(d.width) * size_t(d.height), 256);
+    }
+    const int rc = check_vp8_frames(n, frames); if (rc) return rc;
+    z.work_bytes = uint64_t(vp8_work(n, frames).total);
+    *sizes = z;
+    return WP_OK;
+}
+
+int wp_vp8_batch_gather(int n, const wp_parsed* const* files, const int* frame_index, const wp_vp8_frame* frames,
+                        uint32_t* mb, uint32_t* filt, size_t n_mb_capacity, int16_t* coeff, size_t n_coeff_blocks_capacity,
+                        int n_threads) {
+    if (n < 0 || (n > 0 && (!files || !frames || !mb || !filt))) return fail(WP_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i) {
+        const wp::ParsedFrame* f = lossy_frame(files, frame_index, i);
+        const size_t nmb = f ? size_t(f->vp8.mbw) * size_t(f->vp8.mbh) : 0;
+        if (!f || f->vp8.mbw != frames[i].mbw || f->vp8.mbh != frames[i].mbh || f->vp8.mb.size() != nmb * WP_MB_WORDS || f->vp8.filt.size() != nmb)
+            return fail(WP_ERR_INVALID, "item " + std::to_string(i) + " does not match its descriptor (wp_vp8_batch_layout)");
+        if (!f->vp8.coeff.empty() && !coeff) return fail(WP_ERR_INVALID, "null coefficient slab");
+        if (size_t(frames[i].mb_base) + nmb > n_mb_capacity || size_t(frames[i].coeff_base) + f->vp8.coeff.size() / 16 > n_coeff_blocks_capacity)
+            return fail(WP_ERR_INVALID, "slab too small for item " + std::to_string(i));
+    }
+    if (n_threads <= 0) n_threads = int(std::max(1u, std::thread::hardware_concurrency()));
+    n_threads = std::max(1, std::min(n_threads, n));
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            const wp::ParsedFrame* f = lossy_frame(files, frame_index, i);
+            const wp_vp8_frame& d = frames[i];
+            const size_t nmb = size_t(d.mbw) * size_t(d.mbh);
+            uint32_t* rec = mb + size_t(d.mb_base) * WP_MB_WORDS;
+            std::memcpy(rec, f->vp8.mb.data(), nmb * WP_MB_WORDS * sizeof(uint32_t));
+            std::memcpy(filt + d.mb_base, f->vp8.filt.data(), nmb * sizeof(uint32_t));
+            if (!f->vp8.coeff.empty()) std::memcpy(coeff + size_t(d.coeff_base) * 16, f->vp8.coeff.data(), f->vp8.coeff.size() * sizeof(int16_t));
+        }
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    } catch (const std::exception&) {
+        // fewer threads than asked for: the ones that run share the work
+    }
+    worker();
+    for (auto& t : pool) t.join();
+    return WP_OK;
+}
+
 int wp_parsed_kind(const wp_parsed* p) { return p ? p->kind : -1; }
 int wp_parsed_width(const wp_parsed* p) { return p ? p->width : 0; }
 int wp_parsed_height(const wp_parsed* p) { return p ? p->height : 0; }

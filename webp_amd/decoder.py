@@ -17,7 +17,7 @@ from typing import List, Optional, Union
 import numpy as np
 
 from . import _lib
-from ._lib import Vp8Frame, Vp8lFrame, AlphaFrame, check, lib
+from ._lib import Vp8BatchSizes, Vp8Frame, Vp8lFrame, AlphaFrame, check, lib
 
 
 # ---------------------------------------------------------------- Image.hx mirror
@@ -161,46 +161,35 @@ def parse_many(datas: List[bytes], threads: int = 0) -> List[ParsedFile]:
 
 # ---------------------------------------------------------------- batch assembly
 class LossyBatch:
-    """Packed slabs for a list of lossy frames (the buffers wp_vp8_decode_to_argb[_dev] consumes)."""
+    """Packed slabs for a list of lossy frames (the buffers wp_vp8_decode_to_argb[_dev] consumes), laid out and gathered
+    by the native assembler (wp_vp8_batch_layout / wp_vp8_batch_gather).  `alloc(nbytes)` may supply the host memory of
+    the three slabs (e.g. pinned memory for asynchronous uploads); it returns a writable uint8 numpy array."""
 
-    def __init__(self, frames: List[ParsedFrame], with_alpha: Optional[List[bool]] = None):
+    def __init__(self, frames: List[ParsedFrame], with_alpha: Optional[List[bool]] = None, alloc=None, threads: int = 1):
+        L = lib()
         n = len(frames)
         self.n = n
         self.desc = (Vp8Frame * max(n, 1))()
-        mbs, filts, coeffs = [], [], []
-        mb_base = coeff_base = 0
-        y_off = u_off = v_off = argb_off = alpha_off = 0
-        for i, f in enumerate(frames):
-            d = self.desc[i]
-            d.width, d.height, d.mbw, d.mbh = f.width, f.height, f.mbw, f.mbh
-            d.filter_type = f.filter_type
-            d.has_alpha = 1 if (with_alpha[i] if with_alpha is not None else False) else 0
-            d.mb_base, d.coeff_base = mb_base, coeff_base
-            d.y_off, d.u_off, d.v_off, d.argb_off, d.alpha_off = y_off, u_off, v_off, argb_off, alpha_off
-            mb = f.buf(0, np.uint32)
-            co = f.buf(2, np.int16)
-            mbs.append(mb)
-            filts.append(f.buf(1, np.uint32))
-            coeffs.append(co)
-            nmb = f.mbw * f.mbh
-            assert mb.size == 4 * nmb
-            mb_base += nmb
-            coeff_base += co.size // 16
-            y_off += _align(256 * nmb, 256)
-            u_off += _align(64 * nmb, 256)
-            v_off += _align(64 * nmb, 256)
-            argb_off += _align(4 * f.width * f.height, 256)
-            if d.has_alpha:
-                alpha_off += _align(f.width * f.height, 256)
-        self.mb = np.concatenate(mbs) if mbs else np.zeros(0, np.uint32)
-        self.filt = np.concatenate(filts) if filts else np.zeros(0, np.uint32)
-        self.coeff = np.concatenate(coeffs) if coeffs else np.zeros(0, np.int16)
-        if self.coeff.size == 0:
-            self.coeff = np.zeros(16, np.int16)
-        self.n_mb = mb_base
-        self.n_coeff_blocks = self.coeff.size // 16
-        self.y_bytes, self.u_bytes, self.v_bytes = y_off, u_off, v_off
-        self.argb_bytes, self.alpha_bytes = argb_off, alpha_off
+        files = (ctypes.c_void_p * max(n, 1))(*[f._owner._h for f in frames])
+        index = (ctypes.c_int * max(n, 1))(*[f._index for f in frames])
+        alpha = (ctypes.c_int * max(n, 1))(*[1 if (with_alpha is not None and with_alpha[i]) else 0 for i in range(n)])
+        sizes = Vp8BatchSizes()
+        check(L.wp_vp8_batch_layout(n, files, index, alpha, self.desc, ctypes.byref(sizes)))
+        alloc = alloc or (lambda nbytes: np.empty(nbytes, np.uint8))
+        self.n_mb = int(sizes.n_mb)
+        self.n_coeff_blocks = max(int(sizes.n_coeff_blocks), 1)            # never an empty slab
+        self.mb = alloc(16 * self.n_mb)[:16 * self.n_mb].view(np.uint32)
+        self.filt = alloc(4 * self.n_mb)[:4 * self.n_mb].view(np.uint32)
+        self.coeff = alloc(32 * self.n_coeff_blocks)[:32 * self.n_coeff_blocks].view(np.int16)
+        if int(sizes.n_coeff_blocks) == 0:
+            self.coeff[:] = 0
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        check(L.wp_vp8_batch_gather(n, files, index, self.desc, ptr(self.mb), ptr(self.filt), self.n_mb, ptr(self.coeff),
+                                    self.n_coeff_blocks, threads))
+        self.y_bytes, self.u_bytes, self.v_bytes = int(sizes.y_bytes), int(sizes.u_bytes), int(sizes.v_bytes)
+        self.argb_bytes, self.alpha_bytes = int(sizes.argb_bytes), int(sizes.alpha_bytes)
+        self.work_bytes = int(sizes.work_bytes)
+        self._keep = frames                                                 # the parsed files stay alive with the batch
 
     def input_bytes(self):
         """Bytes the device reads per pass: descriptors + records + coefficients."""

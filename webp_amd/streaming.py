@@ -1,0 +1,150 @@
+"""End-to-end decode of many lossy files: file bytes in host memory -> ARGB (and, when asked, YUV420 planes) in pinned
+host memory, in chunks that move through four overlapping stages:
+
+    host threads: container walk + entropy decode of chunk k+1 (wp_parse_batch)
+    this thread : batch assembly of chunk k into pinned slabs (wp_vp8_batch_layout / _gather), async H2D
+    GPU         : reconstruction, loop filter, finishing pass of chunk k (compute stream)
+    GPU DMA     : D2H of chunk k-1's outputs (copy stream)
+
+Two slots of device / pinned buffers alternate; events order the stages, nothing blocks on the GPU except a slot that is
+still in flight when it comes round again.  This is SURVEY 8(f) rank 1 (host parse threading + H2D), kept out of
+bench.py's `value`, which is the device-resident rate; tools/e2e_bench.py times it."""
+import ctypes
+import queue
+import threading
+from typing import List
+
+import numpy as np
+import torch
+
+from ._lib import Vp8Frame, check, lib
+from .decoder import LossyBatch, parse_many
+
+
+class _Slot:
+    """Grow-only pinned and device buffers of one pipeline slot."""
+
+    def __init__(self, device):
+        self.device = device
+        self.pin = {}
+        self.dev = {}
+        self.done = None            # event: the slot's D2H copies have finished
+
+    def pinned(self, name, nbytes):
+        t = self.pin.get(name)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(max(int(nbytes * 1.25), 256), dtype=torch.uint8, pin_memory=True)
+            self.pin[name] = t
+        return t
+
+    def on_device(self, name, nbytes):
+        t = self.dev.get(name)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(max(int(nbytes * 1.25), 256), dtype=torch.uint8, device=self.device)
+            self.dev[name] = t
+        return t
+
+
+class LossyStream:
+    def __init__(self, device="cuda:0", threads=16, chunk=128, planes=True):
+        self.device = torch.device(device)
+        self.threads, self.chunk, self.planes = threads, chunk, planes
+        lib().wp_init(self.device.index or 0)
+        self.s_in = torch.cuda.Stream(self.device)
+        self.s_compute = torch.cuda.Stream(self.device)
+        self.s_out = torch.cuda.Stream(self.device)
+        self.slots = [_Slot(self.device), _Slot(self.device)]
+
+    def decode(self, datas: List[bytes]):
+        """Returns (argb, items[, y, u, v]): pinned uint8 tensors holding every image's output and, per image, a dict with
+        width, height, mbw, mbh and the byte offsets of its outputs.  Raises WebPError on the first file that does not parse
+        or is not a lossy still."""
+        n = len(datas)
+        chunks = [datas[i:i + self.chunk] for i in range(0, n, self.chunk)]
+        parsed = queue.Queue(maxsize=2)
+
+        def producer():
+            try:
+                for c in chunks:
+                    parsed.put(parse_many(c, self.threads))
+            except BaseException as e:          # handed to the consumer, which re-raises it
+                parsed.put(e)
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        items = []
+        outs = {}                               # name -> [pinned tensor, bytes used]
+
+        def out_slab(name, need):
+            t, used = outs.get(name, (None, 0))
+            if t is None:                       # sized from the first chunk, with headroom; grows by reallocation if a later chunk needs it
+                t = torch.empty(int(need * len(chunks) * 1.1) + 4096, dtype=torch.uint8, pin_memory=True)
+            elif used + need > t.numel():
+                torch.cuda.synchronize(self.device)
+                t2 = torch.empty(int((used + need) * 1.5), dtype=torch.uint8, pin_memory=True)
+                t2[:used] = t[:used]
+                t = t2
+            outs[name] = [t, used]
+            return t, used
+
+        names = ("argb", "y", "u", "v") if self.planes else ("argb",)
+        for k in range(len(chunks)):
+            files = parsed.get()
+            if isinstance(files, BaseException):
+                raise files
+            frames = []
+            for f in files:
+                if f.kind != 0 or not f.frames or f.frames[0].type != 0:
+                    raise ValueError("LossyStream handles lossy still images only")
+                frames.append(f.frames[0])
+            slot = self.slots[k & 1]
+            if slot.done is not None:
+                slot.done.synchronize()         # the slot's previous chunk has left the device
+            order = iter(("mb", "filt", "coeff"))
+            b = LossyBatch(frames, alloc=lambda nbytes: slot.pinned(next(order), nbytes).numpy(), threads=self.threads)
+            desc_bytes = ctypes.sizeof(Vp8Frame) * b.n
+            pd = slot.pinned("desc", desc_bytes)
+            ctypes.memmove(pd.data_ptr(), ctypes.addressof(b.desc), desc_bytes)
+            sizes = {"mb": b.mb.nbytes, "filt": b.filt.nbytes, "coeff": b.coeff.nbytes, "desc": desc_bytes}
+            with torch.cuda.stream(self.s_in):
+                for name, nb in sizes.items():
+                    slot.on_device(name, nb)[:nb].copy_(slot.pin[name][:nb], non_blocking=True)
+                ev_in = torch.cuda.Event()
+                ev_in.record(self.s_in)
+            need = {"argb": b.argb_bytes, "y": b.y_bytes, "u": b.u_bytes, "v": b.v_bytes}
+            dev_out = {name: slot.on_device("out_" + name, need[name]) for name in names}
+            work = slot.on_device("work", max(b.work_bytes, 256))
+            with torch.cuda.stream(self.s_compute):
+                self.s_compute.wait_event(ev_in)
+                pl = [dev_out[p].data_ptr() if self.planes else None for p in ("y", "u", "v")]
+                check(lib().wp_vp8_decode_to_argb_dev(b.n, b.desc, slot.dev["desc"].data_ptr(), slot.dev["mb"].data_ptr(),
+                                                      slot.dev["filt"].data_ptr(), slot.dev["coeff"].data_ptr(), work.data_ptr(),
+                                                      b.work_bytes, pl[0], pl[1], pl[2], None, dev_out["argb"].data_ptr(),
+                                                      ctypes.c_void_p(self.s_compute.cuda_stream)))
+                ev_c = torch.cuda.Event()
+                ev_c.record(self.s_compute)
+            base = {}
+            with torch.cuda.stream(self.s_out):
+                self.s_out.wait_event(ev_c)
+                for name in names:
+                    t, used = out_slab(name, need[name])
+                    t[used:used + need[name]].copy_(dev_out[name][:need[name]], non_blocking=True)
+                    base[name] = used
+                    outs[name][1] = used + need[name]
+                slot.done = torch.cuda.Event()
+                slot.done.record(self.s_out)
+            for i in range(b.n):
+                d = b.desc[i]
+                it = {"width": d.width, "height": d.height, "mbw": d.mbw, "mbh": d.mbh, "argb_off": base["argb"] + d.argb_off}
+                if self.planes:
+                    it.update(y_off=base["y"] + d.y_off, u_off=base["u"] + d.u_off, v_off=base["v"] + d.v_off)
+                items.append(it)
+            slot.keep = (b, files)              # host objects stay alive until the slot is reused
+        th.join()
+        for s in self.slots:
+            if s.done is not None:
+                s.done.synchronize()
+        res = [outs["argb"][0] if outs else torch.empty(0, dtype=torch.uint8), items]
+        if self.planes:
+            res += [outs[p][0] for p in ("y", "u", "v")] if outs else [torch.empty(0, dtype=torch.uint8)] * 3
+        return tuple(res)
