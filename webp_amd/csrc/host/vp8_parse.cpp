@@ -33,11 +33,11 @@ struct BoolReader {
 
     void open(const uint8_t* b, size_t n) { p = b; end = b + n; range_m1 = 254; v = 0; nb = 0; eof = false; }
 
-    struct Norm { uint8_t shift[256], range[256]; };
+    struct Norm { uint16_t e[256]; };        // shift | new range-1 << 8
     static const Norm& norm() {
         static const Norm t = [] {
             Norm n{};
-            for (int i = 0; i < 256; ++i) { n.shift[i] = i < 127 ? wpd_BoolShift[i] : 0; n.range[i] = i < 127 ? wpd_BoolRange[i] : uint8_t(i); }
+            for (int i = 0; i < 256; ++i) n.e[i] = uint16_t(i < 127 ? (wpd_BoolShift[i] | (wpd_BoolRange[i] << 8)) : (i << 8));
             return n;
         }();
         return t;
@@ -52,16 +52,16 @@ struct BoolReader {
         const int pos = nb - 8;
         const bool b = int32_t(uint32_t(v >> pos) << 8) >= int32_t(split << 8);
         if (b) { range_m1 -= int32_t(split); v -= uint64_t(split) << pos; } else { range_m1 = int32_t(split) - 1; }
-        const Norm& t = norm_;
-        nb -= t.shift[range_m1];
-        range_m1 = t.range[range_m1];
+        const uint32_t e = norm_->e[range_m1];
+        nb -= int(e & 0xff);
+        range_m1 = int32_t(e >> 8);
         return b;
     }
     inline int uint(int prob, int n) { int u = 0; for (int i = n - 1; i >= 0; --i) if (bit(prob)) u |= 1 << i; return u; }
     inline int sint(int prob, int n) { const int u = uint(prob, n); return bit(prob) ? -u : u; }
     inline int opt_int(int prob, int n) { return bit(prob) ? sint(prob, n) : 0; }
 
-    const Norm& norm_ = norm();
+    const Norm* norm_ = &norm();
 };
 
 constexpr int kUniform = 128;
@@ -267,8 +267,10 @@ private:
 
     // parseResiduals4, Vp8Decoder.hx:579-637.  Writes dequantised, 16-bit-truncated values in
     // natural order into blk[16]; returns the "non-zero" context flag (first EOB test).
-    int tokens(BoolReader& r, int plane, int ctx, const int* q, bool skip_first, int16_t* blk) {
+    // *stored: OR of the values written (0: the block is still all zero -- a product can truncate to 0).
+    int tokens(BoolReader& r, int plane, int ctx, const int* q, bool skip_first, int16_t* blk, int* stored) {
         const uint8_t (*prob)[3][11] = prob_[plane];
+        *stored = 0;
         int n = skip_first ? 1 : 0;
         const uint8_t* p = prob[kBand[n]][ctx];
         if (!r.bit(p[0])) return 0;
@@ -299,16 +301,14 @@ private:
             int32_t c = v * q[z > 0 ? 1 : 0];
             if (r.bit(kUniform)) c = -c;
             blk[z] = int16_t(uint16_t(uint32_t(c)));          // (c << 16) >> 16
+            *stored |= blk[z];
             if (n == 16 || !r.bit(p[0])) return 1;
         }
         return 1;
     }
 
-    static bool any_nonzero(const int16_t* b) {
-        for (int i = 0; i < 16; ++i) if (b[i]) return true;
-        return false;
-    }
-    void push_block(const int16_t* b) { out_.coeff.insert(out_.coeff.end(), b, b + 16); }
+    // stores a block that holds something and hands the scratch block back zeroed
+    void push_block(int16_t* b) { out_.coeff.insert(out_.coeff.end(), b, b + 16); std::memset(b, 0, 16 * sizeof(int16_t)); }
 
     // inverseWHT16 (Vp8Decoder.hx:960-989) restricted to the question the host needs answered:
     // which of the 16 luma DCs are non-zero (feeds `skip`, hence FilterParam.inner).  int32, untruncated (Q5).
@@ -380,13 +380,12 @@ private:
             const Dequant& dq = dq_[segment_];
             int plane = kPlaneY1SansY2;
             uint32_t dc_nz = 0, ac_nz = 0;
-            int16_t blk[16];
+            int16_t blk[16] = {0};            // all zero whenever tokens() is entered
+            int stored;
             if (i16) {
-                std::memset(blk, 0, sizeof blk);
-                const int nz = tokens(r, kPlaneY2, left_.nz_y16 + up.nz_y16, dq.y2, false, blk);
+                const int nz = tokens(r, kPlaneY2, left_.nz_y16 + up.nz_y16, dq.y2, false, blk, &stored);
                 left_.nz_y16 = up.nz_y16 = uint8_t(nz);
-                dc_nz = wht_nonzero_mask(blk);
-                if (any_nonzero(blk)) { push_block(blk); w2 |= 1u << WP_MB_WHT_BIT; }
+                if (stored) { dc_nz = wht_nonzero_mask(blk); push_block(blk); w2 |= 1u << WP_MB_WHT_BIT; }
                 plane = kPlaneY1WithY2;
             }
             int lnz[4], unz[4];
@@ -394,13 +393,12 @@ private:
             for (int y = 0; y < 4; ++y) {
                 int nz = lnz[y];
                 for (int x = 0; x < 4; ++x) {
-                    std::memset(blk, 0, sizeof blk);
-                    nz = tokens(r, plane, nz + unz[x], dq.y1, i16, blk);
+                    nz = tokens(r, plane, nz + unz[x], dq.y1, i16, blk, &stored);
                     unz[x] = nz;
                     const int n = 4 * y + x;
                     if (nz) ac_nz |= 1u << n;
                     if (!i16 && blk[0] != 0) dc_nz |= 1u << n;
-                    if (any_nonzero(blk)) { push_block(blk); w2 |= 1u << n; }
+                    if (stored) { push_block(blk); w2 |= 1u << n; }
                 }
                 lnz[y] = nz;
             }
@@ -411,13 +409,12 @@ private:
                 for (int y = 0; y < 2; ++y) {
                     int nz = lnz[y + c];
                     for (int x = 0; x < 2; ++x) {
-                        std::memset(blk, 0, sizeof blk);
-                        nz = tokens(r, kPlaneUV, nz + unz[x + c], dq.uv, false, blk);
+                        nz = tokens(r, kPlaneUV, nz + unz[x + c], dq.uv, false, blk, &stored);
                         unz[x + c] = nz;
                         const int n = 16 + c * 2 + y * 2 + x;
                         if (nz) ac_nz |= 1u << n;
                         if (blk[0] != 0) dc_nz |= 1u << n;
-                        if (any_nonzero(blk)) { push_block(blk); w2 |= 1u << n; }
+                        if (stored) { push_block(blk); w2 |= 1u << n; }
                     }
                     lnz[y + c] = nz;
                 }
