@@ -73,7 +73,9 @@ __device__ __forceinline__ int wht_dc_lanes(int v, int l) {
     const int i0 = __shfl(v, c, 16), i1 = __shfl(v, 4 + c, 16), i2 = __shfl(v, 8 + c, 16), i3 = __shfl(v, 12 + c, 16);
     const int a0 = i0 + i3, a1 = i1 + i2, a2 = i1 - i2, a3 = i0 - i3;
     const int m = r == 0 ? a0 + a1 : r == 1 ? a3 + a2 : r == 2 ? a0 - a1 : a3 - a2;      // m[4r + c]
-    const int m0 = __shfl(m, 4 * r, 16), m1 = __shfl(m, 4 * r + 1, 16), m2 = __shfl(m, 4 * r + 2, 16), m3 = __shfl(m, 4 * r + 3, 16);
+    // second pass: the four values of a row sit in one quad of lanes: DPP quad broadcasts, no LDS round trip
+    const int m0 = __builtin_amdgcn_mov_dpp(m, 0x00, 0xf, 0xf, false), m1 = __builtin_amdgcn_mov_dpp(m, 0x55, 0xf, 0xf, false),
+              m2 = __builtin_amdgcn_mov_dpp(m, 0xAA, 0xf, 0xf, false), m3 = __builtin_amdgcn_mov_dpp(m, 0xFF, 0xf, 0xf, false);
     const int dc = m0 + 3;
     const int b0 = dc + m3, b1 = m1 + m2, b2 = m1 - m2, b3 = dc - m3;
     const int o = c == 0 ? b0 + b1 : c == 1 ? b3 + b2 : c == 2 ? b0 - b1 : b3 - b2;
