@@ -81,7 +81,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     dist = None
+    saved_stdout = None
     if world > 1 or os.environ.get("WEBP_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on a 1-GPU box
+        # RCCL prints a version banner on stdout when NCCL_DEBUG=VERSION is set: keep stdout for the one JSON line by
+        # pointing file descriptor 1 at stderr until that line is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(device))
 
@@ -196,8 +202,12 @@ def main():
         line["cpu_baseline"] = cpu_baseline(paths)
     if dist is not None:
         dist.destroy_process_group()
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0:
-        print(json.dumps(line), flush=True)         # the last line of stdout (RCCL may print a version banner before it)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
