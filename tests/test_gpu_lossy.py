@@ -99,7 +99,13 @@ def test_staged_workspace_path_equals_fused(dev_batch):
     db.loopfilter(planes=False)
     db.finish(planes=False, argb=True)
     torch.cuda.synchronize()
-    assert torch.equal(db.argb, ref)
+    for i, n in enumerate(names):
+        d = db.b.desc[i]
+        got, exp = db.argb[d.argb_off:d.argb_off + 4 * d.width * d.height], ref[d.argb_off:d.argb_off + 4 * d.width * d.height]
+        if not torch.equal(got, exp):
+            bad = torch.nonzero(got != exp).flatten()
+            raise AssertionError("staged != fused for %s: %d bytes differ, first at pixel (%d, %d)" % (
+                n, bad.numel(), int(bad[0]) // 4 % d.width, int(bad[0]) // 4 // d.width))
     # the row-major conversion entry point (Tools.toArgb on given planes) agrees with the finishing pass
     db.decode_to_argb(planes=True)
     db.argb.zero_()

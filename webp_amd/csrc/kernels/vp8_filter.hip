@@ -47,7 +47,8 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
         for (int band = 0; band < n_bands; ++band) {
             const uint32_t q = seq + uint32_t(band);
             if (int(q % kFilterWaves) != wave) continue;
-            filter_band<kFilterWaves>(fr, band, n_bands, q, q - 1, wave, progress, lds_all[wave], filt, Rp, Sp);
+            if (fr.filter_type == 1) filter_band<kFilterWaves, true>(fr, band, n_bands, q, q - 1, wave, progress, lds_all[wave], filt, Rp, Sp);
+            else filter_band<kFilterWaves, false>(fr, band, n_bands, q, q - 1, wave, progress, lds_all[wave], filt, Rp, Sp);
         }
         seq += uint32_t(n_bands);
     }

@@ -45,9 +45,9 @@ __device__ __forceinline__ int clamp255(int v) { return clampi(v, 0, 255); }
 // line (its |q2 - q3| is the next one's |p1 - p0|) is computed once.
 
 // filter2, one position (Filter.hx:29-50)
-__device__ __forceinline__ void simple_edge(int p1, int& p0, int& q0, int q1, int level) {
-    const bool on = (absdiff(p0, q0) << 1) + (absdiff(p1, q1) >> 1) <= level;
-    const int a = on ? 3 * (q0 - p0) + clamp127(p1 - q1) : 0;
+__device__ __forceinline__ void simple_edge(int p1, int& p0, int& q0, int q1, int level, bool use) {
+    const bool on = use && (absdiff(p0, q0) << 1) + (absdiff(p1, q1) >> 1) <= level;
+    const int a = on ? __mul24(q0 - p0, 3) + clamp127(p1 - q1) : 0;
     const int a1 = clamp15((a + 4) >> 3);
     const int a2 = clamp15((a + 3) >> 3);
     p0 = clamp255(p0 + a2);
@@ -57,12 +57,12 @@ __device__ __forceinline__ void simple_edge(int p1, int& p0, int& q0, int q1, in
 // filter246, one position (Filter.hx:53-111).  FOUR = inner edge (4-pixel filter), else MB edge (6-pixel).
 template <bool FOUR>
 __device__ __forceinline__ void normal_edge(int p3, int& p2, int& p1, int& p0, int& q0, int& q1, int& q2, int q3,
-                                            int level, int ilevel, int hlevel) {
+                                            int level, int ilevel, int hlevel, bool use) {
     const int m10 = max(absdiff(p1, p0), absdiff(q0, q1));
     const int worst = max(max(max(absdiff(p3, p2), absdiff(p2, p1)), m10), max(absdiff(q1, q2), absdiff(q2, q3)));
-    const bool on = (absdiff(p0, q0) << 1) + (absdiff(p1, q1) >> 1) <= level && worst <= ilevel;
+    const bool on = use && (absdiff(p0, q0) << 1) + (absdiff(p1, q1) >> 1) <= level && worst <= ilevel;
     const bool hev = m10 > hlevel;
-    const int base = 3 * (q0 - p0);
+    const int base = __mul24(q0 - p0, 3);
     const int outer = clamp127(p1 - q1);
     if (FOUR) {
         const int a = on ? base + (hev ? outer : 0) : 0;
@@ -76,7 +76,7 @@ __device__ __forceinline__ void normal_edge(int p3, int& p2, int& p1, int& p0, i
     } else {
         const int w = on ? base + outer : 0;
         const int a = clamp127(w);
-        const int c1 = (27 * a + 63) >> 7, c2 = (18 * a + 63) >> 7, c3 = (9 * a + 63) >> 7;
+        const int c1 = (__mul24(a, 27) + 63) >> 7, c2 = (__mul24(a, 18) + 63) >> 7, c3 = (__mul24(a, 9) + 63) >> 7;
         const int dp0 = hev ? clamp15((w + 3) >> 3) : c1;
         const int dq0 = hev ? clamp15((w + 4) >> 3) : c1;
         const int d1 = hev ? 0 : c2;
@@ -92,26 +92,25 @@ __device__ __forceinline__ void normal_edge(int p3, int& p2, int& p1, int& p0, i
 
 // One line of N = 4 + 16 (luma) or 4 + 8 (chroma) samples crossing the MB edge at index 4 and the
 // inner edges at 8 (and 12, 16 for luma).  Order as in the reference: MB edge first, then inner edges.
-// Edges are written out with constant indices so that the sample array stays in registers.
-template <int N>
-__device__ __forceinline__ void filter_line(int (&v)[N], bool simple, bool mb_edge, bool inner, int level, int ilevel, int hlevel) {
-    if (simple) {
-        if (mb_edge) simple_edge(v[2], v[3], v[4], v[5], level + 4);
-        if (inner) {
-            simple_edge(v[6], v[7], v[8], v[9], level);
-            if constexpr (N == 20) {
-                simple_edge(v[10], v[11], v[12], v[13], level);
-                simple_edge(v[14], v[15], v[16], v[17], level);
-            }
+// Edges are written out with constant indices so that the sample array stays in registers.  "This lane's macroblock
+// has no MB edge / no inner edges" is one more term of the edge's filter mask, not a branch: a branch whose condition
+// differs between the lanes of a wavefront is executed by the wavefront anyway, and merging its results with the
+// untouched samples of the other lanes cost ~30 register moves per line.  SIMPLE is a property of the frame.
+template <int N, bool SIMPLE>
+__device__ __forceinline__ void filter_line(int (&v)[N], bool mb_edge, bool inner, int level, int ilevel, int hlevel) {
+    if constexpr (SIMPLE) {
+        simple_edge(v[2], v[3], v[4], v[5], level + 4, mb_edge);
+        simple_edge(v[6], v[7], v[8], v[9], level, inner);
+        if constexpr (N == 20) {
+            simple_edge(v[10], v[11], v[12], v[13], level, inner);
+            simple_edge(v[14], v[15], v[16], v[17], level, inner);
         }
     } else {
-        if (mb_edge) normal_edge<false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], level + 4, ilevel, hlevel);
-        if (inner) {
-            normal_edge<true>(v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], level, ilevel, hlevel);
-            if constexpr (N == 20) {
-                normal_edge<true>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], level, ilevel, hlevel);
-                normal_edge<true>(v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19], level, ilevel, hlevel);
-            }
+        normal_edge<false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], level + 4, ilevel, hlevel, mb_edge);
+        normal_edge<true>(v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], level, ilevel, hlevel, inner);
+        if constexpr (N == 20) {
+            normal_edge<true>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], level, ilevel, hlevel, inner);
+            normal_edge<true>(v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19], level, ilevel, hlevel, inner);
         }
     }
 }
@@ -119,7 +118,7 @@ __device__ __forceinline__ void filter_line(int (&v)[N], bool simple, bool mb_ed
 // One band.  `q` is the band's sequence number in this workgroup, `q_prev` that of the band above (band > 0), `progress`
 // the workgroup's LDS progress words (one per wavefront, W of them).  The caller has made sure that the band's R tiles
 // are complete and visible.
-template <int W>
+template <int W, bool SIMPLE>
 __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, int n_bands, uint32_t q, uint32_t q_prev, int wave, uint32_t* progress,
                                             FilterWaveLds& lds, const uint32_t* __restrict__ filt, const uint8_t* __restrict__ Rp, uint8_t* Sp) {
     const int lane = threadIdx.x & 63;
@@ -131,7 +130,7 @@ __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, in
     const int hr = l >> 1, hh = l & 1;                    // hand-over: luma row 0..7, 8-byte half
     const int hcr = (l >> 1) & 3;                         // hand-over: chroma row 0..3 (plane = lp, 4-byte half = hh)
     const int mbw = fr.mbw, mbh = fr.mbh;
-    const bool simple = fr.filter_type == 1;
+    constexpr bool simple = SIMPLE;                          // fr.filter_type == 1, resolved by the caller
     const uint8_t* const R = Rp + size_t(fr.mb_base) * kTileBytes;
     uint8_t* const S = Sp + size_t(fr.stile_base) * kTileBytes;
     const int spitch = mbw + 1;
@@ -218,7 +217,7 @@ __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, in
                 unpack4(t32(&T.y[8 + l][pb + 12]), v);
                 const uint4 w = t128(&T.y[8 + l][cb]);
                 unpack4(w.x, v + 4); unpack4(w.y, v + 8); unpack4(w.z, v + 12); unpack4(w.w, v + 16);
-                filter_line<20>(v, simple, x > 0, inner, level, ilevel, hlevel);
+                filter_line<20, SIMPLE>(v, x > 0, inner, level, ilevel, hlevel);
                 t32(&T.y[8 + l][pb + 12]) = pack4i(v);
                 t128(&T.y[8 + l][cb]) = make_uint4(pack4i(v + 4), pack4i(v + 8), pack4i(v + 12), pack4i(v + 16));
             }
@@ -227,7 +226,7 @@ __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, in
                 unpack4(t32(&T.c[lp][4 + lr][pb8 + 4]), v);
                 const uint2 w = t64(&T.c[lp][4 + lr][cb8]);
                 unpack4(w.x, v + 4); unpack4(w.y, v + 8);
-                filter_line<12>(v, false, x > 0, inner, level, ilevel, hlevel);
+                filter_line<12, false>(v, x > 0, inner, level, ilevel, hlevel);
                 t32(&T.c[lp][4 + lr][pb8 + 4]) = pack4i(v);
                 t64(&T.c[lp][4 + lr][cb8]) = make_uint2(pack4i(v + 4), pack4i(v + 8));
             }
@@ -241,7 +240,7 @@ __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, in
                 int v[20];
 #pragma unroll
                 for (int k = 0; k < 20; ++k) v[k] = T.y[4 + k][cb + l];
-                filter_line<20>(v, simple, y > 0, inner, level, ilevel, hlevel);
+                filter_line<20, SIMPLE>(v, y > 0, inner, level, ilevel, hlevel);
 #pragma unroll
                 for (int k = 1; k < 19; ++k) T.y[4 + k][cb + l] = uint8_t(v[k]);
             }
@@ -249,7 +248,7 @@ __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, in
                 int v[12];
 #pragma unroll
                 for (int k = 0; k < 12; ++k) v[k] = T.c[lp][k][cb8 + lr];
-                filter_line<12>(v, false, y > 0, inner, level, ilevel, hlevel);
+                filter_line<12, false>(v, y > 0, inner, level, ilevel, hlevel);
 #pragma unroll
                 for (int k = 1; k < 11; ++k) T.c[lp][k][cb8 + lr] = uint8_t(v[k]);
             }
