@@ -179,7 +179,7 @@ __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, in
         if (has_above && s + 1 < mbw)
             wait_progress(&progress[prev_wave], (q_prev << kSeqShift) | uint32_t(min(s + 3, mbw)));
         if (row_ok && x + 1 >= 0 && x + 1 < mbw) {
-            const size_t o = size_t(x + 1) * kTileBytes;
+            const uint32_t o = uint32_t(x + 1) * uint32_t(kTileBytes);      // 32-bit offset inside the row (mbw <= 1024)
             nx_y = ld_nt(reinterpret_cast<const uint4*>(rrow + o + 16 * l));
             nx_c = ld_nt(reinterpret_cast<const uint2*>(rrow + o + kTileCb + 8 * l));
             nx_fp = frow[x + 1];
@@ -269,7 +269,7 @@ __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, in
         WP_PROF_MARK(4);
         if (act) {
             // ---- 3. emit S tile (x, y): rows -8..7, cols -8..7 relative to the MB, all final ----
-            uint8_t* st = srow + size_t(x) * kTileBytes;
+            uint8_t* st = srow + uint32_t(x) * uint32_t(kTileBytes);
             const uint2 a = t64(&T.y[l][pb + 8]), b = t64(&T.y[l][cb]);
             st_nt(reinterpret_cast<uint4*>(st + 16 * l), make_uint4(a.x, a.y, b.x, b.y));
             st_nt(reinterpret_cast<uint2*>(st + kTileCb + 8 * l), make_uint2(t32(&T.c[lp][lr][pb8 + 4]), t32(&T.c[lp][lr][cb8])));
@@ -288,7 +288,7 @@ __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, in
                     t32(&lds.ring_c[g + 1][lp][hcr][(8 * x + 4) & 31]) = t32(&T.c[lp][8 + hcr][cb8 + 4]);
                 }
             } else {
-                uint8_t* sn = st + size_t(spitch) * kTileBytes;       // S tile (x, y+1); tile row mbh exists
+                uint8_t* sn = st + uint32_t(spitch) * uint32_t(kTileBytes);       // S tile (x, y+1); tile row mbh exists
                 *reinterpret_cast<uint2*>(sn + 16 * hr + 8 * hh) = vy;
                 *reinterpret_cast<uint32_t*>(sn + kTileCb + 64 * lp + 8 * hcr + 4 * hh) = vc;
                 if (x == mbw - 1 && hh) {

@@ -261,6 +261,7 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
     // step s issues: the record of MB x+2 and, from the record of MB x+1 (fetched by the previous call), the
     // coefficients of MB x+1.
     const uint4* mb_row = mb + size_t(fr.mb_base) + size_t(row_ok ? y : 0) * mbw;
+    uint8_t* const Rrow = R + size_t(row_ok ? y : 0) * mbw * kTileBytes;      // R tiles of this lane's MB row
     const int16_t* const cfr = coeff + size_t(fr.coeff_base) * 16;
     uint4 rec_n1 = make_uint4(0, 0, 0, 0), rec_n2 = make_uint4(0, 0, 0, 0);     // records of MB x+1, x+2
     uint4 nl0 = make_uint4(0, 0, 0, 0), nl1 = make_uint4(0, 0, 0, 0);           // luma block l of MB x+1
@@ -277,14 +278,14 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
         if (row_ok && x_ + 1 >= 0 && x_ + 1 < mbw) {
             const uint32_t w2n = rec_n1.z;
             const int whtn = (w2n >> WP_MB_WHT_BIT) & 1;
-            const int16_t* cbn = cfr + size_t(rec_n1.w) * 16;
+            const int16_t* cbn = cfr + size_t(rec_n1.w) * 16;      // a block index can need more than 32 bits once scaled: 64-bit
             if ((w2n >> l) & 1) {
-                const uint4* bp = reinterpret_cast<const uint4*>(cbn + size_t(whtn + __popc(w2n & ((1u << l) - 1u))) * 16);
+                const uint4* bp = reinterpret_cast<const uint4*>(cbn + uint32_t(whtn + __popc(w2n & ((1u << l) - 1u))) * 16u);
                 nl0 = ld_nt(bp); nl1 = ld_nt(bp + 1);
             }
             if (whtn) nwv = uint32_t(int(cbn[l]));
             if (chroma_lane && ((w2n >> cn) & 1)) {
-                const uint4* bp = reinterpret_cast<const uint4*>(cbn + size_t(whtn + __popc(w2n & ((1u << cn) - 1u))) * 16);
+                const uint4* bp = reinterpret_cast<const uint4*>(cbn + uint32_t(whtn + __popc(w2n & ((1u << cn) - 1u))) * 16u);
                 nc0 = ld_nt(bp); nc1 = ld_nt(bp + 1);
             }
         }
@@ -315,7 +316,7 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
                 const uint8_t* src0 = R + size_t(y - 1) * mbw * kTileBytes
                                     + (l < 4 ? 240 + 4 * l : l < 6 ? kTileCb + 56 + 4 * (l - 4) : kTileCr + 56 + 4 * (l - 6));
                 if (s == 0) top_a = *reinterpret_cast<const uint32_t*>(src0);
-                if (s + 1 < mbw) top_b = *reinterpret_cast<const uint32_t*>(src0 + size_t(s + 1) * kTileBytes);
+                if (s + 1 < mbw) top_b = *reinterpret_cast<const uint32_t*>(src0 + uint32_t(s + 1) * uint32_t(kTileBytes));
             }
         }
 
@@ -486,7 +487,7 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
         if (act) {
             // ---- write back (Vp8Decoder.hx:812-821): the MB sits complete in the LDS tile; lane l stores
             //      luma row l and one chroma row, so the group emits the 384-byte tile as three full lines ----
-            uint8_t* tile = R + (size_t(y) * mbw + x) * kTileBytes;
+            uint8_t* tile = Rrow + uint32_t(x) * uint32_t(kTileBytes);     // 32-bit offset inside the row (mbw <= 1024)
             const uint8_t* yr = T.y[1 + l];
             st_nt(reinterpret_cast<uint4*>(tile + 16 * l), make_uint4(tile32(const_cast<uint8_t*>(yr), 4), tile32(const_cast<uint8_t*>(yr), 8),
                                                                   tile32(const_cast<uint8_t*>(yr), 12), tile32(const_cast<uint8_t*>(yr), 16)));
