@@ -328,18 +328,19 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
 
         uint32_t ev[4] = {0, 0, 0, 0}, od[4] = {0, 0, 0, 0};          // luma residual of block l
         {
+            // No per-lane branches here: a lane without a stored block holds zeros from the prefetch, and zero
+            // coefficients give zero residuals ((0 + 4) >> 3), so every lane runs the same code; only whole-wavefront
+            // conditions (nobody has a WHT / nobody has anything to transform) skip work.
             int c[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) c[k] = 0;
+            unpack_block(cl0, cl1, c);
             const bool present = act && ((w2 >> l) & 1);
-            if (present) unpack_block(cl0, cl1, c);
             int dc16 = 0;
             if (__builtin_amdgcn_ballot_w64(act && has_wht) != 0) {
                 const int wv = (act && has_wht) ? wv_cur : 0;
                 dc16 = wht_dc_lanes(wv, l);
                 if (act && has_wht) c[0] = dc16; else dc16 = 0;
             }
-            if (present || dc16 != 0) idct_residual(c, ev, od);
+            if (__builtin_amdgcn_ballot_w64(present || dc16 != 0) != 0) idct_residual(c, ev, od);
         }
         uint32_t cev[4] = {0, 0, 0, 0}, cod[4] = {0, 0, 0, 0};
         {
@@ -348,13 +349,11 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
             // is only run when some lane of the wavefront has a chroma block with AC (rare below ~q85).
             const bool cpres = act && chroma_lane && ((w2 >> cn) & 1);
             const bool c_ac = cpres && (((cc0.x >> 16) | cc0.y | cc0.z | cc0.w | cc1.x | cc1.y | cc1.z | cc1.w) != 0);
-            if (__builtin_amdgcn_ballot_w64(c_ac) != 0) {
-                if (cpres) {
-                    int c[16];
-                    unpack_block(cc0, cc1, c);
-                    idct_residual(c, cev, cod);
-                }
-            } else if (cpres) {
+            if (__builtin_amdgcn_ballot_w64(c_ac) != 0) {           // lanes without a chroma block hold zeros: zero residuals
+                int c[16];
+                unpack_block(cc0, cc1, c);
+                idct_residual(c, cev, cod);
+            } else {
                 const int v = (int(int16_t(cc0.x & 0xffff)) + 4) >> 3;
                 const uint32_t p = as_u32(__builtin_amdgcn_cvt_pk_i16(v, v));
 #pragma unroll
