@@ -27,9 +27,6 @@ __device__ __forceinline__ uint32_t splat4(int v) { return __builtin_amdgcn_perm
 // 32 bits of the full-rate 24-bit multiply equal the wrapping 32-bit product (v_mul_lo_u32 is quarter rate).
 __device__ __forceinline__ int mul16(int a, int c) { return __mul24(a, c) >> 16; }
 
-typedef short short2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t as_u32(short2_t v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ short2_t as_s2(uint32_t v) { return __builtin_bit_cast(short2_t, v); }
 
 // Residual of one 4x4 block: inverseDCT4 without the "+ prediction, clip8" tail
 // (Vp8Decoder.hx:905-935).  Row j comes back as two packed int16 pairs:
@@ -94,14 +91,6 @@ __device__ __forceinline__ uint32_t avg3p(uint32_t a, uint32_t b, uint32_t c) {
 #define WP_ALB(hi, lo, n) __builtin_amdgcn_alignbyte((hi), (lo), (n))
 // byte selector: selector bytes 0..3 pick from `lo`, 4..7 from `hi`
 #define WP_PERM(hi, lo, sel) __builtin_amdgcn_perm((hi), (lo), (sel))
-
-// clamp two int16 pairs (pixels 0,2 and pixels 1,3) to 0..255 and interleave them into four bytes
-__device__ __forceinline__ uint32_t clip_pack(short2_t p02, short2_t p13) {
-    uint32_t l8, h8;                                   // v_sat_pk_u8_i16: two int16 -> two bytes (low half), clamped to 0..255
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(l8) : "v"(as_u32(p02)));
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(h8) : "v"(as_u32(p13)));
-    return WP_PERM(h8, l8, 0x05010400u);               // bytes: l8[0], h8[0], l8[1], h8[1]
-}
 
 // clip8(pred + residual) for one row of four pixels (Vp8Decoder.hx:930-933, 991-996).
 __device__ __forceinline__ uint32_t add_clip_row(uint32_t pred, uint32_t even, uint32_t odd) {

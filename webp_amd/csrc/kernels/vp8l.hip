@@ -37,7 +37,7 @@ __device__ __forceinline__ uint32_t add_px(uint32_t a, uint32_t b) {
     return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
 }
 // per-byte floor((a + b) / 2)  (Transform.hx:283-285 avg2)
-__device__ __forceinline__ uint32_t avg_px(uint32_t a, uint32_t b) { return (a & b) + (((a ^ b) & 0xfefefefeu) >> 1); }
+__device__ __forceinline__ uint32_t avg_px(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0u); }   // v_lerp_u8: (a + b + 0) >> 1 per byte
 
 // ---------------------------------------------------------------- streaming transforms
 __global__ __launch_bounds__(256)
@@ -143,23 +143,16 @@ __device__ __forceinline__ uint32_t predict_px(int mode, uint32_t L, uint32_t T,
     case 11: {   // select: l = sum|TL - T|, t = sum|TL - L|; L if l < t else T
         const uint32_t l = __builtin_amdgcn_sad_u8(TL, T, 0u), t = __builtin_amdgcn_sad_u8(TL, L, 0u);
         return l < t ? L : T; }
+    // the two clamped modes work on the channel pairs (0,2) and (1,3) in packed 16-bit arithmetic
     case 12: {   // clampAddSubtractFull(L, T, TL) per channel
-        uint32_t r = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int a = (L >> (8 * k)) & 0xff, b = (T >> (8 * k)) & 0xff, c = (TL >> (8 * k)) & 0xff;
-            r |= uint32_t(clamp255i(a + b - c)) << (8 * k);
-        }
-        return r; }
-    case 13: {   // clampAddSubtractHalf(avg2(L, T), TL): a + trunc((a - b) / 2)  (Q10: C-style division)
+        const short2_t e = as_s2(L & 0x00ff00ffu) + as_s2(T & 0x00ff00ffu) - as_s2(TL & 0x00ff00ffu);
+        const short2_t o = as_s2((L >> 8) & 0x00ff00ffu) + as_s2((T >> 8) & 0x00ff00ffu) - as_s2((TL >> 8) & 0x00ff00ffu);
+        return clip_pack(e, o); }
+    case 13: {   // clampAddSubtractHalf(avg2(L, T), TL): a + trunc((a - b) / 2)  (Q10: C-style division, rounds towards zero)
         const uint32_t av = avg_px(L, T);
-        uint32_t r = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int a = (av >> (8 * k)) & 0xff, b = (TL >> (8 * k)) & 0xff;
-            r |= uint32_t(clamp255i(a + (a - b) / 2)) << (8 * k);
-        }
-        return r; }
+        const short2_t ae = as_s2(av & 0x00ff00ffu), ao = as_s2((av >> 8) & 0x00ff00ffu);
+        const short2_t de = ae - as_s2(TL & 0x00ff00ffu), dO = ao - as_s2((TL >> 8) & 0x00ff00ffu);
+        return clip_pack(ae + ((de - (de >> 15)) >> 1), ao + ((dO - (dO >> 15)) >> 1)); }
     default: return 0u;
     }
 }

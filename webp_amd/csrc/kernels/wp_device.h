@@ -62,6 +62,18 @@ __device__ __forceinline__ void st_nt(uint4* p, uint4 v) { const u32x4_t w = {v.
 __device__ __forceinline__ void st_nt(uint2* p, uint2 v) { const u32x2_t w = {v.x, v.y}; __builtin_nontemporal_store(w, reinterpret_cast<u32x2_t*>(p)); }
 #endif
 
+// Packed 16-bit helpers shared by the lossy and the lossless kernels.
+typedef short short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t as_u32(short2_t v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ short2_t as_s2(uint32_t v) { return __builtin_bit_cast(short2_t, v); }
+// clamp two int16 pairs (bytes 0,2 and bytes 1,3 of a pixel group) to 0..255 and interleave them into four bytes
+__device__ __forceinline__ uint32_t clip_pack(short2_t p02, short2_t p13) {
+    uint32_t l8, h8;                                   // v_sat_pk_u8_i16: two int16 -> two bytes (low half), clamped to 0..255
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(l8) : "v"(as_u32(p02)));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(h8) : "v"(as_u32(p13)));
+    return __builtin_amdgcn_perm(h8, l8, 0x05010400u);  // bytes: l8[0], h8[0], l8[1], h8[1]
+}
+
 // Optional per-phase cycle profile of the wavefront kernels (tuning builds only: -DWP_PROFILE).  Wave 0 of workgroup 0
 // accumulates s_memtime deltas per phase and adds them to wp_prof[] at the end of each band; tools read the symbol.
 #ifdef WP_PROFILE
