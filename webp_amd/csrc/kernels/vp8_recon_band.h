@@ -360,31 +360,32 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
         __builtin_amdgcn_s_setprio(1);
 
         if (act) {
-            // ---- prepareYBR (Vp8Decoder.hx:541-577): left column, then top row ----
+            // ---- prepareYBR (Vp8Decoder.hx:541-577): left columns, top rows, the rows-4/8/12 copy of the top-right
+            //      (:572-576).  Every lane has a fixed set of small copy jobs and none of them reads what another one
+            //      writes, so all LDS reads are issued first and all writes after one wait (the literal order --
+            //      left column, then top row, then the copies -- is three dependent LDS round trips) ----
             {
-                const uint8_t fillL = 0x81;
-                T.y[l][3] = x == 0 ? fillL : T.y[l][19];
-                if (l == 0) T.y[16][3] = x == 0 ? fillL : T.y[16][19];
-                if (l < 9) {
-                    T.c[l][3] = x == 0 ? fillL : T.c[l][11];
-                    T.c[l][19] = x == 0 ? fillL : T.c[l][27];
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (y == 0) {
-                if (l < 5) tile32(T.y[0], 4 + 4 * l) = 0x7f7f7f7fu;
-                if (l == 5) { T.y[0][3] = 0x7f; T.c[0][3] = 0x7f; T.c[0][19] = 0x7f; }
-                if (l == 6 || l == 7) tile32(T.c[0], 4 + 4 * (l - 6)) = 0x7f7f7f7fu;
-                if (l == 8 || l == 9) tile32(T.c[0], 20 + 4 * (l - 8)) = 0x7f7f7f7fu;
-            } else {
+                const int lc = min(l, 8);
+                uint32_t va = T.y[l][19], vb = T.y[16][19], vc1 = T.c[lc][11], vc2 = T.c[lc][27];     // last column of the previous MB
+                // top border from the ring: lanes 0-3 luma dwords, 6-9 chroma dwords; lanes 4 and 10-12 the top-right dword
+                // for rows 0, 4, 8 and 12
+                const bool tr_job = l == 4 || (l >= 10 && l <= 12);
                 const uint32_t* slot = lds.ring[g][x & 3];
-                if (l < 4) tile32(T.y[0], 4 + 4 * l) = slot[l];
-                if (l == 4) tile32(T.y[0], 20) = x == mbw - 1 ? splat4(int(slot[3] >> 24)) : lds.ring[g][(x + 1) & 3][0];
-                if (l == 6 || l == 7) tile32(T.c[0], 4 + 4 * (l - 6)) = slot[4 + (l - 6)];
-                if (l == 8 || l == 9) tile32(T.c[0], 20 + 4 * (l - 8)) = slot[6 + (l - 8)];
+                uint32_t rv = slot[l < 4 ? l : (l >= 6 && l <= 9) ? l - 2 : 3];
+                const uint32_t nxt = lds.ring[g][(x + 1) & 3][0];
+                if (tr_job) rv = x == mbw - 1 ? splat4(int(rv >> 24)) : nxt;
+                if (x == 0) { va = 0x81; vb = 0x81; vc1 = 0x81; vc2 = 0x81; }
+                if (y == 0) {
+                    rv = 0x7f7f7f7fu;
+                    if (l == 0) { va = 0x7f; vc1 = 0x7f; vc2 = 0x7f; }                          // the corners belong to the top row
+                }
+                T.y[l][3] = uint8_t(va);
+                if (l == 0) T.y[16][3] = uint8_t(vb);
+                if (l < 9) { T.c[l][3] = uint8_t(vc1); T.c[l][19] = uint8_t(vc2); }
+                uint8_t* dst = l < 4 ? &T.y[0][4 + 4 * l] : l == 4 ? &T.y[0][20] : l < 8 ? &T.c[0][4 + 4 * (l - 6)]
+                             : l < 10 ? &T.c[0][20 + 4 * (l - 8)] : &T.y[4 * (l - 9)][20];
+                if (l < 5 || (l >= 6 && l <= 12)) tile32(dst, 0) = rv;
             }
-            __builtin_amdgcn_wave_barrier();
-            if (l >= 1 && l <= 3) tile32(T.y[4 * l], 20) = tile32(T.y[0], 20);   // rows 4/8/12 keep the MB's top-right (:572-576)
             __builtin_amdgcn_wave_barrier();
 
             WP_PROF_MARK(2);
