@@ -258,30 +258,42 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
     uint4 nc0 = make_uint4(0, 0, 0, 0), nc1 = make_uint4(0, 0, 0, 0);           // chroma block of MB x+1 (chroma lanes)
     const int cn = 16 + (l & 3) + ((l & 8) ? 4 : 0);                            // lanes 0-3: Cb blocks, 8-11: Cr blocks
     const bool chroma_lane = (l & 4) == 0;
+    // Every lane issues every load of the prefetch, every step: a lane that has nothing to fetch (outside the frame, no
+    // stored block, no WHT) reads a block of zeros instead.  No branches, nothing to clear beforehand, and -- the count of
+    // loads per step being fixed -- the compiler can wait for the top-row loads issued before them without also
+    // waiting for these.
+    const uint4* const zero = wp_zero_block;
     auto prefetch = [&](int s_) {
         const int x_ = s_ - 2 * g;
-        rec_n1 = rec_n2;
-        if (row_ok && x_ + 2 >= 0 && x_ + 2 < mbw) rec_n2 = mb_row[x_ + 2];
-        nl0 = make_uint4(0, 0, 0, 0); nl1 = make_uint4(0, 0, 0, 0); nwv = 0;
-        nc0 = make_uint4(0, 0, 0, 0); nc1 = make_uint4(0, 0, 0, 0);
-        if (row_ok && x_ + 1 >= 0 && x_ + 1 < mbw) {
-            const uint32_t w2n = rec_n1.z;
-            const int whtn = (w2n >> WP_MB_WHT_BIT) & 1;
-            const int16_t* cbn = cfr + size_t(rec_n1.w) * 16;      // a block index can need more than 32 bits once scaled: 64-bit
-            if ((w2n >> l) & 1) {
-                const uint4* bp = reinterpret_cast<const uint4*>(cbn + uint32_t(whtn + __popc(w2n & ((1u << l) - 1u))) * 16u);
-                nl0 = ld_nt(bp); nl1 = ld_nt(bp + 1);
-            }
-            if (whtn) nwv = uint32_t(int(cbn[l]));
-            if (chroma_lane && ((w2n >> cn) & 1)) {
-                const uint4* bp = reinterpret_cast<const uint4*>(cbn + uint32_t(whtn + __popc(w2n & ((1u << cn) - 1u))) * 16u);
-                nc0 = ld_nt(bp); nc1 = ld_nt(bp + 1);
-            }
-        }
+        rec_n1 = rec_n2;                                            // all zero for a lane whose MB x+1 is outside the frame
+        const bool in2 = row_ok && x_ + 2 >= 0 && x_ + 2 < mbw;
+        rec_n2 = *(in2 ? mb_row + (x_ + 2) : zero);
+        const uint32_t w2n = rec_n1.z;
+        const int whtn = (w2n >> WP_MB_WHT_BIT) & 1;
+        const int16_t* cbn = cfr + size_t(rec_n1.w) * 16;      // a block index can need more than 32 bits once scaled: 64-bit
+        const uint4* lp = ((w2n >> l) & 1) ? reinterpret_cast<const uint4*>(cbn + uint32_t(whtn + __popc(w2n & ((1u << l) - 1u))) * 16u) : zero;
+        nl0 = ld_nt(lp); nl1 = ld_nt(lp + 1);
+        nwv = uint32_t(int(*(whtn ? cbn + l : reinterpret_cast<const int16_t*>(zero))));
+        const uint4* cp = (chroma_lane && ((w2n >> cn) & 1)) ? reinterpret_cast<const uint4*>(cbn + uint32_t(whtn + __popc(w2n & ((1u << cn) - 1u))) * 16u) : zero;
+        nc0 = ld_nt(cp); nc1 = ld_nt(cp + 1);
     };
     prefetch(-2);
     prefetch(-1);
-    settle(rec_n1); settle(rec_n2); settle(nl0); settle(nl1); settle(nwv); settle(nc0); settle(nc1);
+    // Top context of group 0: the bottom rows of the band above, read from its output tiles one step ahead (like the
+    // coefficient blocks, so that no load result is needed in the middle of a step).  Lanes 0-3 fetch the last luma row,
+    // 4-5 the last Cb row, 6-7 the last Cr row of MB (column, y-1); top_n holds column s+1 at the top of step s.
+    const bool top_lane = has_above && g == 0 && l < 8;
+    const uint8_t* const top_src = R + size_t(has_above ? y - 1 : 0) * mbw * kTileBytes
+                                 + (l < 4 ? 240 + 4 * l : l < 6 ? kTileCb + 56 + 4 * (l - 4) : kTileCr + 56 + 4 * (l - 6));
+    uint32_t top_n = 0;
+    if (has_above) {
+        wait_progress(&progress[prev_wave], (q_prev << kSeqShift) | uint32_t(min(2, mbw)));
+        if (top_lane) {
+            lds.ring[0][0][l] = *reinterpret_cast<const uint32_t*>(top_src);
+            if (mbw > 1) top_n = *reinterpret_cast<const uint32_t*>(top_src + kTileBytes);
+        }
+    }
+    settle(rec_n1); settle(rec_n2); settle(nl0); settle(nl1); settle(nwv); settle(nc0); settle(nc1); settle(top_n);
     uint32_t pending_publish = 0;
 
     WP_PROF_MARK(9);
@@ -292,22 +304,17 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
         const uint4 rec = act ? rec_n1 : make_uint4(0, 0, 0, 0);
         const uint4 cl0 = nl0, cl1 = nl1, cc0 = nc0, cc1 = nc1;
         const int wv_cur = int(nwv);
-        prefetch(s);
 
-        // ---- top context of group 0 comes from the band above, through the output tiles: issue the
-        //      loads now, park them in the LDS ring after the residuals have been computed ----
-        uint32_t top_a = 0, top_b = 0;
-        const bool fetch_top = has_above && s < mbw && g == 0 && l < 8;
-        if (has_above && s < mbw) {
-            wait_progress(&progress[prev_wave], (q_prev << kSeqShift) | uint32_t(min(s + 2, mbw)));
-            if (fetch_top) {
-                // last luma row / last Cb row / last Cr row of the tile of MB (s+1, y-1)
-                const uint8_t* src0 = R + size_t(y - 1) * mbw * kTileBytes
-                                    + (l < 4 ? 240 + 4 * l : l < 6 ? kTileCb + 56 + 4 * (l - 4) : kTileCr + 56 + 4 * (l - 6));
-                if (s == 0) top_a = *reinterpret_cast<const uint32_t*>(src0);
-                if (s + 1 < mbw) top_b = *reinterpret_cast<const uint32_t*>(src0 + uint32_t(s + 1) * uint32_t(kTileBytes));
+        // ---- top context of group 0: park the column fetched during the previous step in the LDS ring, fetch the next ----
+        if (has_above && s + 1 < mbw) {
+            if (top_lane) lds.ring[0][(s + 1) & 3][l] = top_n;
+            if (s + 2 < mbw) {
+                wait_progress(&progress[prev_wave], (q_prev << kSeqShift) | uint32_t(min(s + 3, mbw)));
+                if (top_lane) top_n = *reinterpret_cast<const uint32_t*>(top_src + uint32_t(s + 2) * uint32_t(kTileBytes));
             }
         }
+
+        prefetch(s);           // nothing loaded in this step is used before the step's end
 
         WP_PROF_MARK(0);
         // ---- residuals (independent of the neighbours) ----
@@ -350,10 +357,6 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
             }
         }
         WP_PROF_MARK(1);
-        if (fetch_top) {
-            if (s == 0) lds.ring[0][0][l] = top_a;
-            if (s + 1 < mbw) lds.ring[0][(s + 1) & 3][l] = top_b;
-        }
         __builtin_amdgcn_wave_barrier();
         // Issue priority rises along the step: the prediction chain (and most of all the i4 mini-steps, which keep
         // few lanes busy) is what the next step and the band below wait for, the residuals above are not.
@@ -466,7 +469,7 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
         //      (s_waitcnt vmcnt(0)) does not stall on store acknowledgements ----
         WP_PROF_MARK(5);
         __builtin_amdgcn_s_setprio(0);
-        settle(rec_n2); settle(nl0); settle(nl1); settle(nwv); settle(nc0); settle(nc1);   // the prefetches have had the whole step to land; wait for them before this step's stores go out
+        settle(rec_n2); settle(nl0); settle(nl1); settle(nwv); settle(nc0); settle(nc1); settle(top_n);   // the prefetches have had the whole step to land; wait for them before this step's stores go out
         if (has_below) {
             if (pending_publish) publish_progress(&progress[wave], pending_publish);
             const int done = s - 2 * (kBandRows - 1) + 1;
