@@ -104,6 +104,7 @@ class LossyPipeline:
         self.s_finish = torch.cuda.Stream(self.device)
         self.max_in_flight = max_in_flight
         self._queued = []               # events of the steps not yet known to be complete, oldest first
+        self._prev_finish = None        # event of the most recent finishing pass
         self._last_finish = {}          # id(batch) -> event of its last finishing pass
         cur = torch.cuda.current_stream(self.device)
         self.s_main.wait_stream(cur)
@@ -128,8 +129,11 @@ class LossyPipeline:
             r0 = mark(self.s_main)
             db.recon(planes=False)
             r1 = mark(self.s_main)
-            if fin is not None and not unfiltered:
-                self.s_main.wait_event(fin)
+            # The loop filter waits for the previous finishing pass whichever batch that belonged to: on the same batch it
+            # rewrites the S tiles that pass reads, and in any case a persistent kernel that starts while the streaming
+            # pass holds the GPU gets its workgroups placed piecemeal and runs far slower (tools/overlap_delay.py).
+            if self._prev_finish is not None:
+                self.s_main.wait_event(self._prev_finish)
             f0 = mark(self.s_main)
             db.loopfilter(planes=False)
             f1 = mark(self.s_main)
@@ -145,6 +149,7 @@ class LossyPipeline:
         if timing is not None:
             timing.append((r0, r1, f0, f1, c0, c1))
         self._last_finish[id(db)] = done
+        self._prev_finish = done
         self._queued.append(done)
         return done
 
@@ -154,3 +159,4 @@ class LossyPipeline:
         cur.wait_stream(self.s_finish)
         self._last_finish.clear()
         self._queued.clear()
+        self._prev_finish = None
