@@ -157,3 +157,22 @@ def test_predictor_maximum_dimensions(shape):
     t = _tiles(rng, w, h, bits, list(range(14)))
     got = _run_chain([dict(width=w, height=h, coded_width=w, pix=pix, transforms=[(0, bits, w, t)])])[0]
     assert np.array_equal(got, oracle.inverse_predictor(w, bits, t, pix, h))
+
+
+def test_inconsistent_transform_lists_are_refused():
+    """Every buffer extent the kernels use follows from the transform list, so the entry point checks it before any
+    launch: widths must chain from `width` to `coded_width`, tile / palette data must be long enough."""
+    from webp_amd._lib import WebPError
+    rng = np.random.default_rng(9)
+    w, h, bits = 37, 23, 3
+    pix = rng.integers(0, 256, 4 * w * h, dtype=np.uint8)
+    t = _tiles(rng, w, h, bits)
+    ok = dict(width=w, height=h, coded_width=w, pix=pix, transforms=[(0, bits, w, t)])
+    assert _run_chain([ok])[0].size == 4 * w * h
+    for bad, msg in ((dict(ok, transforms=[(0, bits, w, t[:-4])]), "transform data too short"),
+                     (dict(ok, transforms=[(0, bits, w + 1, t)]), "bad transform"),
+                     (dict(ok, coded_width=w - 1), "coded_width"),
+                     (dict(ok, transforms=[(3, 1, w, np.zeros(60, np.uint8))], coded_width=(w + 1) // 2,
+                           pix=np.zeros(4 * ((w + 1) // 2) * h, np.uint8)), "transform data too short")):
+        with pytest.raises(WebPError, match=msg):
+            _run_chain([bad])

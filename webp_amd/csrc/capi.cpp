@@ -280,9 +280,27 @@ int wp_vp8l_inverse_dev(int n, const wp_vp8l_frame* fh, const wp_vp8l_frame* fd,
         if (a.width <= 0 || a.height <= 0 || a.coded_width <= 0 || a.n_transforms < 0 || a.n_transforms > WP_VP8L_MAX_TRANSFORMS ||
             (a.pix_off & 15) || (a.out_off & 15) || (a.tmp_off & 15))
             return fail(WP_ERR_INVALID, "bad wp_vp8l_frame at index " + std::to_string(i));
-        for (int k = 0; k < a.n_transforms; ++k)
-            if (a.t[k].type < 0 || a.t[k].type > 3 || a.t[k].bits < 0 || a.t[k].bits > 9 || (a.t[k].data_off & 3))
+        // The kernels derive every buffer extent from the transform list: check that the list is consistent with the frame
+        // (widths chain from `width` down to `coded_width` as in Vp8LDecoder.hx:58-121) and that each transform's data is
+        // as long as the kernel that undoes it will read.
+        long long w = a.width;
+        for (int k = 0; k < a.n_transforms; ++k) {
+            const wp_vp8l_transform& t = a.t[k];
+            if (t.type < 0 || t.type > 3 || t.bits < 0 || t.bits > 9 || (t.data_off & 3) || t.old_width != w)
                 return fail(WP_ERR_INVALID, "bad transform in wp_vp8l_frame " + std::to_string(i));
+            unsigned long long need = 0;
+            if (t.type == 0 || t.type == 1) {
+                if (t.bits < 2) return fail(WP_ERR_INVALID, "bad transform in wp_vp8l_frame " + std::to_string(i));
+                const long long tw = (w + (1LL << t.bits) - 1) >> t.bits, th = ((long long)a.height + (1LL << t.bits) - 1) >> t.bits;
+                need = 4ull * (unsigned long long)tw * (unsigned long long)th;
+            } else if (t.type == 3) {
+                if (t.bits > 3) return fail(WP_ERR_INVALID, "bad transform in wp_vp8l_frame " + std::to_string(i));
+                need = 4ull << (8 >> t.bits);
+                w = (w + (1LL << t.bits) - 1) >> t.bits;
+            }
+            if (t.data_len < need) return fail(WP_ERR_INVALID, "transform data too short in wp_vp8l_frame " + std::to_string(i));
+        }
+        if (w != a.coded_width) return fail(WP_ERR_INVALID, "coded_width of wp_vp8l_frame " + std::to_string(i) + " does not follow from its transforms");
     }
     if (n == 0) return WP_OK;
     const int e = wpk_launch_vp8l(n, fh, fd, d_pix, d_aux, d_tmp, d_out, swizzle, hipStream_t(stream));
