@@ -215,6 +215,20 @@ void wp_parsed_free(wp_parsed* p);
  * throughput long before the kernels do).  out[i] receives the parsed object or NULL, status[i] its wp_status;
  * returns 0 if every file parsed, else the first failing status (wp_last_error holds that file's message). */
 int wp_parse_batch(int n, const uint8_t* const* data, const size_t* len, int n_threads, wp_parsed** out, int* status);
+/* The same loop as wp_parse_batch, but running in the background so that a caller can consume the files in index order
+ * while later ones are still being parsed (one work queue for the whole set: no thread idles while another finishes a
+ * large file, whatever the size of the chunks the caller consumes).  At most `window` files beyond the last index waited
+ * for are started (0 = no limit): that bounds the memory held by parsed files nobody has consumed yet, and lets the
+ * allocator reuse what the consumer has freed.  data / len / out / status must stay valid until
+ * wp_parse_job_finish.  wp_parse_job_wait blocks until files [0, upto) are done (parsed or failed) and returns 0, or the
+ * first failing status among them.  wp_parse_job_finish stops handing out files, joins the threads and frees the job
+ * (files not yet started stay unparsed; parsed objects in out[] stay the caller's, to be released with wp_parsed_free). */
+typedef struct wp_parse_job wp_parse_job;
+int wp_parse_job_start(int n, const uint8_t* const* data, const size_t* len, int n_threads, int window, wp_parsed** out,
+                       int* status, wp_parse_job** job);
+int wp_parse_job_wait(wp_parse_job* job, int upto);
+int wp_parse_job_finish(wp_parse_job* job);
+
 /* Batch assembly for the lossy path: what `reconstruct`'s prologue and the per-MB capture of the filter parameters
  * leave behind for one frame (Vp8Decoder.hx:772-808, 348-353), laid side by side for n frames so that one
  * device call handles them.  files[i] / frame_index[i] (NULL = frame 0 everywhere) name lossy frames of parsed files.

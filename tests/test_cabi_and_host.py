@@ -219,3 +219,25 @@ def test_batch_layout_and_gather():
     hs2 = (C.c_void_p * 1)(lossless._h)
     with pytest.raises(WebPError, match="not a lossy frame"):
         check(L.wp_vp8_batch_layout(1, hs2, None, None, desc, C.byref(sizes)))
+
+
+def test_parse_job_delivers_files_in_order_while_parsing():
+    """wp_parse_job_*: a background parse whose results are taken in index order; errors surface at the chunk that holds
+    the bad file; closing early leaves nothing behind."""
+    import glob
+    from webp_amd import WebPError, parse
+    from webp_amd.decoder import ParseJob
+    datas = [open(p, "rb").read() for p in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "inputs", "*.webp")))]
+    ref = [(f.kind, f.width, f.height, len(f.frames)) for f in (parse(d) for d in datas)]
+    with ParseJob(datas * 2, 3) as job:
+        got = job.take(4) + job.take(9) + job.take(9) + job.take(10 ** 6)
+    assert [(f.kind, f.width, f.height, len(f.frames)) for f in got] == ref * 2
+    bad = [datas[0], b"RIFF\x04\x00\x00\x00WEBP", datas[1], datas[2]]
+    with ParseJob(bad, 2) as job:
+        assert len(job.take(1)) == 1
+        with pytest.raises(WebPError, match="file 1"):
+            job.take(3)
+    with ParseJob(datas * 4, 2) as job:          # closed with most files never taken
+        job.take(2)
+    with ParseJob([], 2) as job:
+        assert job.take(5) == []

@@ -14,7 +14,7 @@ from webp_amd.streaming import LossyStream
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench_data", "lossy1080_*.webp")))
 datas = [open(paths[i % len(paths)], "rb").read() for i in range(n)]
 torch.cuda.init(); torch.zeros(1, device="cuda:0")

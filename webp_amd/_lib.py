@@ -84,6 +84,9 @@ def lib():
     L.wp_parsed_free.argtypes = [vp]
     L.wp_parse_batch.argtypes = [i32, vp, vp, i32, vp, vp]
     L.wp_parsed_free.restype = None
+    L.wp_parse_job_start.argtypes = [i32, vp, vp, i32, i32, vp, vp, ctypes.POINTER(vp)]
+    L.wp_parse_job_wait.argtypes = [vp, i32]
+    L.wp_parse_job_finish.argtypes = [vp]
     L.wp_vp8_batch_layout.argtypes = [i32, vp, vp, vp, vp, ctypes.POINTER(Vp8BatchSizes)]
     L.wp_vp8_batch_gather.argtypes = [i32, vp, vp, vp, vp, vp, sz, vp, sz, i32]
     for f in ("wp_parsed_kind", "wp_parsed_width", "wp_parsed_height", "wp_parsed_nframes"):

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -551,6 +552,105 @@ int wp_parse_batch(int n, const uint8_t* const* data, const size_t* len, int n_t
     }
     return first;
 }
+// ---- background parse job ----
+struct wp_parse_job {
+    int n = 0;
+    const uint8_t* const* data = nullptr;
+    const size_t* len = nullptr;
+    wp_parsed** out = nullptr;
+    int* status = nullptr;
+    std::atomic<int> next{0};
+    std::atomic<int> n_active{0};       // n while the job runs, 0 once it is being closed
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<char> done;             // guarded by m
+    int done_prefix = 0;                // files [0, done_prefix) are done; guarded by m
+    int allow = 0;                      // files [0, allow) may be started (bounds the parsed-but-unconsumed memory); guarded by m
+    int window = 0;
+    std::vector<std::string> msg;
+    std::vector<std::thread> pool;
+
+    void work() {
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return i < allow; });
+            }
+            if (i >= n_active.load()) break;        // the job is being closed
+            int rc = WP_ERR_NOMEM;
+            wp_parsed* p = new (std::nothrow) wp_parsed();
+            if (p) {
+                try {
+                    rc = (!data[i] && len[i]) ? WP_ERR_INVALID : wp::parse_webp(data[i], len[i], *p, msg[size_t(i)]);
+                } catch (const std::exception&) {
+                    rc = WP_ERR_NOMEM; msg[size_t(i)].clear();
+                }
+                if (rc) { delete p; p = nullptr; }
+            }
+            out[i] = p;
+            status[i] = rc;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                done[size_t(i)] = 1;
+                while (done_prefix < n && done[size_t(done_prefix)]) ++done_prefix;
+            }
+            cv.notify_all();
+        }
+    }
+};
+
+int wp_parse_job_start(int n, const uint8_t* const* data, const size_t* len, int n_threads, int window, wp_parsed** out,
+                       int* status, wp_parse_job** job) {
+    if (!job) return fail(WP_ERR_INVALID, "null job pointer");
+    *job = nullptr;
+    if (n < 0 || (n > 0 && (!data || !len || !out || !status))) return fail(WP_ERR_INVALID, "bad argument");
+    wp_parse_job* j = new (std::nothrow) wp_parse_job();
+    if (!j) return fail(WP_ERR_NOMEM, "out of memory");
+    try {
+        j->n = n; j->data = data; j->len = len; j->out = out; j->status = status;
+        j->n_active.store(n);
+        j->window = window > 0 ? window : n;
+        j->allow = std::min(n, j->window);
+        j->done.assign(size_t(n), 0);
+        j->msg.resize(size_t(n));
+        for (int i = 0; i < n; ++i) { out[i] = nullptr; status[i] = WP_OK; }
+        if (n_threads <= 0) n_threads = int(std::max(1u, std::thread::hardware_concurrency()));
+        n_threads = std::max(1, std::min(n_threads, std::max(n, 1)));
+        for (int t = 0; t < n_threads && n > 0; ++t) {
+            try { j->pool.emplace_back([j] { j->work(); }); } catch (const std::exception&) { break; }
+        }
+        if (n > 0 && j->pool.empty()) { delete j; return fail(WP_ERR_NOMEM, "could not start a parse thread"); }
+    } catch (const std::bad_alloc&) {
+        delete j;
+        return fail(WP_ERR_NOMEM, "out of memory");
+    }
+    *job = j;
+    return WP_OK;
+}
+
+int wp_parse_job_wait(wp_parse_job* j, int upto) {
+    if (!j || upto < 0 || upto > j->n) return fail(WP_ERR_INVALID, "bad argument");
+    {
+        std::unique_lock<std::mutex> lk(j->m);
+        if (upto + j->window > j->allow) { j->allow = std::min(j->n, upto + j->window); j->cv.notify_all(); }   // the window slides with the consumer
+        j->cv.wait(lk, [&] { return j->done_prefix >= upto; });
+    }
+    for (int i = 0; i < upto; ++i)
+        if (j->status[i]) return fail(j->status[i], "file " + std::to_string(i) + ": " + (j->msg[size_t(i)].empty() ? std::string("out of memory") : j->msg[size_t(i)]));
+    return WP_OK;
+}
+
+int wp_parse_job_finish(wp_parse_job* j) {
+    if (!j) return WP_OK;
+    j->n_active.store(0);                // files nobody has started stay unparsed (out[i] == NULL)
+    j->next.store(j->n);
+    { std::lock_guard<std::mutex> lk(j->m); j->allow = j->n; }
+    j->cv.notify_all();
+    for (auto& t : j->pool) t.join();
+    delete j;
+    return WP_OK;
+}
+
 namespace {
 const wp::ParsedFrame* lossy_frame(const wp_parsed* const* files, const int* frame_index, int i) {
     const wp_parsed* p = files[i];

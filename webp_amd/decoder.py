@@ -159,6 +159,57 @@ def parse_many(datas: List[bytes], threads: int = 0) -> List[ParsedFile]:
     return files
 
 
+class ParseJob:
+    """Background parse of a list of files on native threads (wp_parse_job_*): `take(upto)` blocks until files [0, upto)
+    are parsed and returns the ParsedFile objects not handed out yet.  One work queue serves the whole list, so consuming
+    in small chunks does not idle threads at chunk ends; at most `window` files beyond the last index asked for are started
+    (0 = no limit)."""
+
+    def __init__(self, datas: List[bytes], threads: int = 0, window: int = 0):
+        L = lib()
+        self.n = len(datas)
+        self._datas = datas                                              # the buffers must outlive the job
+        self._ptrs = (ctypes.c_char_p * max(self.n, 1))(*datas)
+        self._lens = (ctypes.c_size_t * max(self.n, 1))(*[len(d) for d in datas])
+        self._out = (ctypes.c_void_p * max(self.n, 1))()
+        self._status = (ctypes.c_int * max(self.n, 1))()
+        self._job = ctypes.c_void_p()
+        self._taken = 0
+        check(L.wp_parse_job_start(self.n, self._ptrs, self._lens, threads, window, self._out, self._status, ctypes.byref(self._job)))
+
+    def take(self, upto: int) -> List["ParsedFile"]:
+        upto = min(upto, self.n)
+        rc = lib().wp_parse_job_wait(self._job, upto)
+        files = [ParsedFile(handle=self._out[i]) for i in range(self._taken, upto) if self._out[i]]
+        for i in range(self._taken, upto):
+            self._out[i] = None                                          # now owned by the ParsedFile
+        self._taken = upto
+        check(rc)
+        return files
+
+    def close(self):
+        if self._job:
+            lib().wp_parse_job_finish(self._job)
+            self._job = ctypes.c_void_p()
+            for i in range(self._taken, self.n):                         # parsed but never taken
+                if self._out[i]:
+                    lib().wp_parsed_free(self._out[i])
+                    self._out[i] = None
+            self._taken = self.n
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---------------------------------------------------------------- batch assembly
 class LossyBatch:
     """Packed slabs for a list of lossy frames (the buffers wp_vp8_decode_to_argb[_dev] consumes), laid out and gathered

@@ -1,7 +1,7 @@
 """End-to-end decode of many lossy files: file bytes in host memory -> ARGB (and, when asked, YUV420 planes) in pinned
 host memory, in chunks that move through four overlapping stages:
 
-    host threads: container walk + entropy decode of chunk k+1 (wp_parse_batch)
+    host threads: container walk + entropy decode of the files ahead (wp_parse_job_*: one work queue for all files)
     this thread : batch assembly of chunk k into pinned slabs (wp_vp8_batch_layout / _gather), async H2D
     GPU         : reconstruction, loop filter, finishing pass of chunk k (compute stream)
     GPU DMA     : D2H of chunk k-1's outputs (copy stream)
@@ -10,15 +10,13 @@ Two slots of device / pinned buffers alternate; events order the stages, nothing
 still in flight when it comes round again.  This is SURVEY 8(f) rank 1 (host parse threading + H2D), kept out of
 bench.py's `value`, which is the device-resident rate; tools/e2e_bench.py times it."""
 import ctypes
-import queue
-import threading
 from typing import List
 
 import numpy as np
 import torch
 
 from ._lib import Vp8Frame, check, lib
-from .decoder import LossyBatch, parse_many
+from .decoder import LossyBatch, ParseJob
 
 
 class _Slot:
@@ -46,7 +44,7 @@ class _Slot:
 
 
 class LossyStream:
-    def __init__(self, device="cuda:0", threads=16, chunk=128, planes=True):
+    def __init__(self, device="cuda:0", threads=16, chunk=32, planes=True):
         self.device = torch.device(device)
         self.threads, self.chunk, self.planes = threads, chunk, planes
         lib().wp_init(self.device.index or 0)
@@ -61,17 +59,7 @@ class LossyStream:
         or is not a lossy still."""
         n = len(datas)
         chunks = [datas[i:i + self.chunk] for i in range(0, n, self.chunk)]
-        parsed = queue.Queue(maxsize=2)
-
-        def producer():
-            try:
-                for c in chunks:
-                    parsed.put(parse_many(c, self.threads))
-            except BaseException as e:          # handed to the consumer, which re-raises it
-                parsed.put(e)
-
-        th = threading.Thread(target=producer, daemon=True)
-        th.start()
+        job = ParseJob(datas, self.threads, window=3 * self.chunk)     # one work queue; chunks are taken in index order
         items = []
         outs = {}                               # name -> [pinned tensor, bytes used]
 
@@ -89,9 +77,7 @@ class LossyStream:
 
         names = ("argb", "y", "u", "v") if self.planes else ("argb",)
         for k in range(len(chunks)):
-            files = parsed.get()
-            if isinstance(files, BaseException):
-                raise files
+            files = job.take(min(n, (k + 1) * self.chunk))
             frames = []
             for f in files:
                 if f.kind != 0 or not f.frames or f.frames[0].type != 0:
@@ -140,7 +126,7 @@ class LossyStream:
                     it.update(y_off=base["y"] + d.y_off, u_off=base["u"] + d.u_off, v_off=base["v"] + d.v_off)
                 items.append(it)
             slot.keep = (b, files)              # host objects stay alive until the slot is reused
-        th.join()
+        job.close()
         for s in self.slots:
             if s.done is not None:
                 s.done.synchronize()
