@@ -170,8 +170,15 @@ int wp_vp8_decode_to_argb_dev(int n, const wp_vp8_frame* frames_host, const wp_v
 /* VP8L inverse transform chain + RGBA->ARGB swizzle.  Replaces Transform.hx inversePredictor /
  * inverseCrossColor / inverseSubtractGreen / inverseColorIndexing, the driver loop
  * Vp8LDecoder.hx:395-401 and the swizzle WebPDecoder.hx:109-123.
- * d_pix is consumed (transforms run in place where the reference does). swizzle != 0 applies the
- * final RGBA->ARGB byte rotation (0 leaves RGBA, which is what readAlpha consumes). */
+ * d_pix is consumed (transforms run in place where the reference does).  `swizzle` selects what the
+ * last pass writes at out_off: WP_SWIZZLE_NONE R,G,B,A as decoded; WP_SWIZZLE_ARGB the rotated
+ * A,R,G,B of WebPDecoder.hx:109-123; WP_SWIZZLE_GREEN one byte per pixel, the green channel, which
+ * is all readAlpha keeps of a VP8L-coded ALPH image (WebPDecoder.hx:330-336) -- feed it to
+ * wp_alpha_unfilter with src_is_vp8l_rgba = 0, or use it as the alpha plane directly when the
+ * ALPH filter is 0. */
+#define WP_SWIZZLE_NONE 0
+#define WP_SWIZZLE_ARGB 1
+#define WP_SWIZZLE_GREEN 2
 int wp_vp8l_inverse_dev(int n, const wp_vp8l_frame* frames_host, const wp_vp8l_frame* d_frames,
                         uint8_t* d_pix, const uint8_t* d_aux, uint8_t* d_tmp, uint8_t* d_out,
                         int swizzle, void* stream);

@@ -114,6 +114,30 @@ def test_full_chain_with_swizzle():
     assert np.array_equal(g, e)
 
 
+def test_green_only_output_is_the_green_channel():
+    """WP_SWIZZLE_GREEN: the last pass keeps what readAlpha keeps of a VP8L-coded ALPH image (WebPDecoder.hx:330-336).
+    Sizes cover every pixel count mod 4 (the kernel packs four pixels per store) and a colour-indexed image, whose last
+    pass reads the temporary slab."""
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    cases, want = [], []
+    for (w, h) in [(1, 1), (2, 1), (3, 1), (5, 1), (7, 3), (64, 2), (203, 131)]:
+        pix = rng.integers(0, 256, 4 * w * h, dtype=np.uint8)
+        t = _tiles(rng, w, h, 3, list(range(14)))
+        cases.append(dict(width=w, height=h, coded_width=w, pix=pix, transforms=[(2, 0, w, np.zeros(0, np.uint8)), (0, 3, w, t)]))
+        want.append(oracle.inverse_subtract_green(oracle.inverse_predictor(w, 3, t, pix, h))[1::4])
+    w, h, bits = 37, 11, 1
+    pw = (w + 1) >> 1
+    pix = rng.integers(0, 256, 4 * pw * h, dtype=np.uint8)
+    pal = rng.integers(0, 256, 4 * 16, dtype=np.uint8)
+    cases.append(dict(width=w, height=h, coded_width=pw, pix=pix, transforms=[(3, bits, w, pal)]))
+    want.append(oracle.inverse_color_indexing(w, bits, pal, pix, h)[1::4])
+    got = _run_chain(cases, swizzle=2)
+    for c, g, e in zip(cases, got, want):
+        n = c["width"] * c["height"]
+        assert np.array_equal(g[:n], e), (c["width"], c["height"])
+
+
 @pytest.mark.parametrize("rgba", [False, True])
 def test_alpha_unfilter_modes(rgba):
     from oracle import oracle

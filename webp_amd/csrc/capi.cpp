@@ -276,6 +276,7 @@ int wp_vp8l_inverse_dev(int n, const wp_vp8l_frame* fh, const wp_vp8l_frame* fd,
                         uint8_t* d_tmp, uint8_t* d_out, int swizzle, void* stream) {
     int rc = ensure_init(); if (rc) return rc;
     if (n < 0 || (n > 0 && (!fh || !fd || !d_pix || !d_out))) return fail(WP_ERR_INVALID, "bad argument");
+    if (swizzle < WP_SWIZZLE_NONE || swizzle > WP_SWIZZLE_GREEN) return fail(WP_ERR_INVALID, "bad swizzle");
     for (int i = 0; i < n; ++i) {
         const wp_vp8l_frame& a = fh[i];
         if (a.width <= 0 || a.height <= 0 || a.coded_width <= 0 || a.n_transforms < 0 || a.n_transforms > WP_VP8L_MAX_TRANSFORMS ||
@@ -446,7 +447,8 @@ int wp_vp8l_inverse(int n, const wp_vp8l_frame* frames, const uint8_t* pix, size
         const wp_vp8l_frame& a = frames[i];
         if (a.width <= 0 || a.height <= 0 || a.coded_width <= 0) return fail(WP_ERR_INVALID, "bad wp_vp8l_frame");
         if (size_t(a.pix_off) + size_t(4) * a.coded_width * a.height > pix_len) return fail(WP_ERR_INVALID, "pix slab too small");
-        if (size_t(a.out_off) + size_t(4) * a.width * a.height > out_len) return fail(WP_ERR_INVALID, "out slab too small");
+        if (size_t(a.out_off) + size_t(swizzle == WP_SWIZZLE_GREEN ? 1 : 4) * a.width * a.height > out_len)
+            return fail(WP_ERR_INVALID, "out slab too small");
         for (int k = 0; k < a.n_transforms && k < WP_VP8L_MAX_TRANSFORMS; ++k)
             if (size_t(a.t[k].data_off) + size_t(a.t[k].data_len) > aux_len) return fail(WP_ERR_INVALID, "aux slab too small");
         tmp_len = std::max(tmp_len, size_t(a.tmp_off) + size_t(4) * a.width * a.height);

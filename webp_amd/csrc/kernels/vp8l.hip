@@ -109,17 +109,33 @@ void vp8l_color_indexing_kernel(const wp_vp8l_frame* __restrict__ frames, int pa
     }
 }
 
-// final copy into the result slab, with the RGBA -> ARGB byte rotation of WebPDecoder.hx:109-123
+// final copy into the result slab: as is, with the RGBA -> ARGB byte rotation of WebPDecoder.hx:109-123, or green only
 __global__ __launch_bounds__(256)
 void vp8l_finish_kernel(const wp_vp8l_frame* __restrict__ frames, const uint8_t* pix, const uint8_t* tmp, uint8_t* out, int swizzle) {
     const wp_vp8l_frame& fr = frames[blockIdx.y];
     const Loc loc = locate(fr, -1);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(loc.in_tmp ? tmp + fr.tmp_off : pix + fr.pix_off);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(out + fr.out_off);
     const long long total = (long long)fr.width * fr.height;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    if (swizzle == WP_SWIZZLE_GREEN) {
+        // the alpha plane is the green channel of a VP8L-coded ALPH image (WebPDecoder.hx:330-336): one byte per pixel,
+        // four pixels per lane so that loads are 16 bytes and stores whole words
+        uint8_t* d8 = out + fr.out_off;
+        for (long long q = first; q < ((total + 3) >> 2); q += stride) {
+            const long long i = q * 4;
+            if (i + 4 <= total) {
+                const uint4 v = *reinterpret_cast<const uint4*>(src + i);
+                *reinterpret_cast<uint32_t*>(d8 + i) = __builtin_amdgcn_perm(v.y, v.x, 0x0c0c0501) | __builtin_amdgcn_perm(v.w, v.z, 0x05010c0c);
+            } else {
+                for (long long k = i; k < total; ++k) d8[k] = uint8_t(src[k] >> 8);
+            }
+        }
+        return;
+    }
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out + fr.out_off);
+    for (long long i = first; i < total; i += stride) {
         const uint32_t v = src[i];
-        dst[i] = swizzle ? ((v << 8) | (v >> 24)) : v;
+        dst[i] = swizzle == WP_SWIZZLE_ARGB ? ((v << 8) | (v >> 24)) : v;
     }
 }
 

@@ -341,9 +341,10 @@ def decode_batch(files: List[ParsedFile]):
         lb = None
         if coded:
             lb = LosslessBatch([t[2] for t in coded], alpha_image=True)
+            # the last pass of the chain writes the green channel only: that is all readAlpha keeps (WebPDecoder.hx:330-336)
             rgba = np.empty(lb.out_bytes, np.uint8)
             check(L.wp_vp8l_inverse(lb.n, lb.desc, _np_ptr(lb.pix), lb.pix.size, _np_ptr(lb.aux), lb.aux.size,
-                                    _np_ptr(rgba), rgba.size, 0))
+                                    _np_ptr(rgba), rgba.size, 2))
         desc = (AlphaFrame * len(alpha_frames))()
         srcs, src_off, dst_off, ci = [], 0, 0, 0
         for i, (_, _, fr) in enumerate(alpha_frames):
@@ -353,8 +354,8 @@ def decode_batch(files: List[ParsedFile]):
             if fr.alpha_is_vp8l:
                 o = int(lb.desc[ci].out_off)
                 ci += 1
-                s = rgba[o:o + 4 * d.width * d.height]
-                d.src_is_vp8l_rgba = 1
+                s = rgba[o:o + d.width * d.height]
+                d.src_is_vp8l_rgba = 0
             else:
                 s = fr.buf(4)
                 d.src_is_vp8l_rgba = 0
