@@ -5,8 +5,8 @@ One "step" = one pass of the device pipeline (reconstruction, loop filter, finis
 both the filtered YUV420 planes and ARGB) over a batch of synthetic encoded 1920x1080 VP8 images whose packed macroblock
 / coefficient / filter buffers are already resident in HBM (the host entropy decode and the H2D copy happen once, before
 the timed region).  Successive steps are software-pipelined over two HIP streams (webp_amd.device.LossyPipeline): the
-memory-bound finishing pass of step k runs while the issue-bound reconstruction of step k+1 has started; every step
-does all of its work and the timed region ends with both streams drained.  `--serial` runs the steps on one stream
+memory-bound finishing pass of step k runs, in two halves, beside the issue-bound reconstruction and loop filter of step
+k+1; every step does all of its work and the timed region ends with both streams drained.  `--serial` runs the steps on one stream
 instead (each kernel alone on the GPU); `--alone` adds the single-stream figure to the pipelined run's JSON line.
 Metric: decoded Mpix/s, counting visible pixels, whole job over all GPUs.
 
@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--pattern", default="lossy1080_*.webp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one stream per step, no overlap between steps (kernel times as when each runs alone)")
+    ap.add_argument("--split", type=float, default=0.6, help="share of a step's frames whose finishing pass runs beside the next reconstruction (the rest: beside the next loop filter)")
+    ap.add_argument("--finish-delay-us", type=float, default=40.0, help="how long a finishing pass is held back so that the persistent kernel of its phase is dispatched first")
     ap.add_argument("--alone", action="store_true", help="after the timed region also time the single-stream fused call (config.serial_ms_per_step)")
     args = ap.parse_args()
 
@@ -101,7 +103,7 @@ def main():
         torch.cuda.synchronize()
 
     from webp_amd.device import LossyPipeline
-    pipe = None if args.serial else LossyPipeline(device)
+    pipe = None if args.serial else LossyPipeline(device, split=args.split, finish_delay_us=args.finish_delay_us)
 
     marks = []                                       # per step: timing events around each kernel, on its launch stream
 
@@ -135,10 +137,26 @@ def main():
     #      of the dominant kernel.  In the pipelined run a reconstruction shares the GPU with the previous step's
     #      finishing pass, so its duration here is longer than when it runs alone (`--serial`, profiles/*serial*). ----
     acc = [0.0, 0.0, 0.0]
+    finish_launches = 0
+    halves = [0.0, 0.0, 0]                          # finishing pass beside reconstruction / beside the loop filter
     for m in marks:
-        for k in range(3):
-            acc[k] += m[2 * k].elapsed_time(m[2 * k + 1])
-    t_recon, t_filter, t_conv = (a / len(marks) for a in acc)
+        if isinstance(m, dict):                      # pipelined: the finishing pass of a step is two launches (one, for the last step)
+            acc[0] += m["r0"].elapsed_time(m["r1"])
+            acc[1] += m["f0"].elapsed_time(m["f1"])
+            if "ca" in m:
+                ha, hb = m["c0"].elapsed_time(m["ca"]), m["cb"].elapsed_time(m["c1"])
+                acc[2] += ha + hb
+                halves[0] += ha; halves[1] += hb; halves[2] += 1
+                finish_launches += 2
+            else:
+                acc[2] += m["c0"].elapsed_time(m["c1"])
+                finish_launches += 1
+        else:
+            for k in range(3):
+                acc[k] += m[2 * k].elapsed_time(m[2 * k + 1])
+            finish_launches += 1
+    t_recon, t_filter, t_conv = (a / len(marks) for a in acc)          # per step
+    finish_per_step = finish_launches / len(marks)
     serial_ms = None
     if args.alone and pipe is not None:              # the same steps on one stream (no overlap), for reference
         db.decode_to_argb(); torch.cuda.synchronize()
@@ -155,20 +173,23 @@ def main():
            "vp8_finish_kernel": 2 * yuv_bytes + argb_bytes}       # tiles in, row-major planes + ARGB out
     times = {"vp8_recon_kernel": t_recon, "vp8_filter_kernel": t_filter, "vp8_finish_kernel": t_conv}
     dom = max(times, key=times.get)
-    achieved = alg[dom] / (times[dom] * 1e-3) / 1e9
+    achieved = alg[dom] / (times[dom] * 1e-3) / 1e9                    # bytes per step / time per step = bytes per launch / time per launch
+    launches = finish_per_step if dom == "vp8_finish_kernel" else 1.0
     # HBM traffic of that kernel from the PMC counters: measured by a separate rocprofv3 --pmc run of this same command
     # (tools/pmc.sh + tools/pmc_traffic.list), committed under profiles/; scaled if --images differs from that run.
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        traffic = int(tj["kernels"][dom]["hbm_bytes"] * args.images / tj["images_per_launch"])
+        traffic = int(tj["kernels"][dom]["hbm_bytes"] * args.images / tj["images_per_launch"] / launches)
     except Exception:
         pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(times[dom], 4),
+                "alg_bytes_per_launch": int(alg[dom] / launches), "avg_launch_ms": round(times[dom] / launches, 4),
+                "launches_per_step": round(launches, 3),
                 "stages_ms": {k: round(v, 4) for k, v in times.items()},
                 "stages_GBs": {k: round(alg[k] / (times[k] * 1e-3) / 1e9, 2) for k in times},
+                "finish_halves_ms": [round(halves[0] / halves[2], 4), round(halves[1] / halves[2], 4)] if halves[2] else None,
                 "pipeline_alg_bytes_per_px": round((in_bytes + yuv_bytes + argb_bytes) / px_per_step, 3),
                 "pipeline_frac": round((in_bytes + yuv_bytes + argb_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
@@ -195,7 +216,8 @@ def main():
                        "macroblocks_per_gpu": n_mb, "coeff_blocks_per_mb": round(batch.n_coeff_blocks / max(n_mb, 1), 3),
                        "host_parse_ms_per_image": round(1e3 * t_parse, 2),
                        "step_pipelining": "none (--serial)" if pipe is None else
-                                          "2 HIP streams: finishing pass of step k overlaps reconstruction of step k+1",
+                                          "2 HIP streams, 2 phases: finishing pass of step k (first %d %% of the frames) beside reconstruction of step k+1, "
+                                          "the rest beside its loop filter; workspaces alternate" % round(100 * args.split),
                        "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 4)},
             "roofline": roofline}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -152,6 +152,14 @@ int wp_vp8_finish_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame
                       const void* d_work, size_t work_bytes, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
                       const uint8_t* d_alpha, uint8_t* d_argb, void* stream);
 
+/* The same for frames [first, first + count) of the batch only (the descriptors and the workspace are
+ * still those of the whole batch).  Lets a caller spread the memory-bound finishing pass of one batch
+ * over the reconstruction and the loop filter of the next ("pipelining steps"). */
+int wp_vp8_finish_range_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
+                            int first, int count, const void* d_work, size_t work_bytes,
+                            uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
+                            const uint8_t* d_alpha, uint8_t* d_argb, void* stream);
+
 /* YUV420 (row-major, MB-padded) -> tightly packed A,R,G,B.  Replaces Tools.toArgb (Tools.hx:6-48).
  * d_alpha may be NULL (all frames opaque); frames with has_alpha == 0 get A = 0xFF. */
 int wp_yuv420_to_argb_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,

@@ -116,9 +116,11 @@ def test_staged_workspace_path_equals_fused(dev_batch):
         assert torch.equal(db.argb[d.argb_off:d.argb_off + 4 * d.width * d.height], ref[d.argb_off:d.argb_off + 4 * d.width * d.height]), n
 
 
-def test_pipelined_steps_equal_serial(dev_batch):
-    """LossyPipeline (finishing pass of one step on a second stream while the next step reconstructs) gives the same
-    bytes as the serial path, for the same batch resubmitted and for two batches alternating."""
+@pytest.mark.parametrize("split", [0.5, 0.0, 0.3, 1.0])
+def test_pipelined_steps_equal_serial(dev_batch, split):
+    """LossyPipeline (the finishing pass of one step, in two frame ranges, on a second stream beside reconstruction and
+    loop filter of the next step; alternating workspaces) gives the same bytes as the serial path, for the same batch
+    resubmitted and for two batches alternating."""
     import glob
     import os
     import torch
@@ -138,7 +140,7 @@ def test_pipelined_steps_equal_serial(dev_batch):
         refs.append([t.clone() for t in (d.argb, d.y, d.u, d.v)])
         for t in (d.argb, d.y, d.u, d.v):
             t.zero_()
-    pipe = LossyPipeline()
+    pipe = LossyPipeline(split=split)
     for k in range(7):
         pipe.submit((db, db2)[k & 1] if k < 4 else db2)
     pipe.drain()
@@ -160,6 +162,9 @@ def test_workspace_checks():
     with pytest.raises(WebPError, match="workspace too small"):
         check(lib().wp_vp8_recon_dev(db.b.n, db.b.desc, db.frames.data_ptr(), db.mb.data_ptr(), db.coeff.data_ptr(),
                                      db.work.data_ptr(), db.work_bytes - 1, None, None, None, None))
+    with pytest.raises(WebPError, match="frame range outside the batch"):
+        check(lib().wp_vp8_finish_range_dev(db.b.n, db.b.desc, db.frames.data_ptr(), 1, 2, db.work.data_ptr(), db.work_bytes,
+                                            None, None, None, None, db.argb.data_ptr(), None))
     saved = db.b.desc[1].stile_base
     db.b.desc[1].stile_base = 0
     with pytest.raises(WebPError, match="wp_vp8_plan"):

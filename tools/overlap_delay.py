@@ -18,6 +18,7 @@ class Delayed(LossyPipeline):
     def __init__(self, d_recon, d_finish):
         super().__init__("cuda:0")
         self.d_recon, self.d_finish = d_recon, d_finish
+        self._last_finish = {}          # this experiment keeps the single-workspace schedule LossyPipeline had before it alternated workspaces
 
     def submit(self, db):
         fin = self._last_finish.get(id(db))

@@ -221,21 +221,27 @@ int wp_vp8_loopfilter_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd,
     return WP_OK;
 }
 
-int wp_vp8_finish_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const void* d_work, size_t work_bytes,
-                      uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, const uint8_t* d_alpha, uint8_t* d_argb, void* stream) {
+int wp_vp8_finish_range_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, int first, int count, const void* d_work, size_t work_bytes,
+                            uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, const uint8_t* d_alpha, uint8_t* d_argb, void* stream) {
     int rc = ensure_init(); if (rc) return rc;
     rc = check_vp8_frames(n, fh); if (rc) return rc;
-    if (n == 0) return WP_OK;
+    if (first < 0 || count < 0 || first > n || count > n - first) return fail(WP_ERR_INVALID, "frame range outside the batch");
+    if (n == 0 || count == 0) return WP_OK;
     if (!fd) return fail(WP_ERR_INVALID, "null device pointer");
     const bool planes = d_y || d_u || d_v;
     if (planes && !(d_y && d_u && d_v)) return fail(WP_ERR_INVALID, "give all three planes or none");
     if (!planes && !d_argb) return WP_OK;
     if (d_argb)
-        for (int i = 0; i < n; ++i)
+        for (int i = first; i < first + count; ++i)
             if (fh[i].has_alpha && !d_alpha) return fail(WP_ERR_INVALID, "frame has alpha but no alpha slab was given");
-    Vp8Work w;
+    Vp8Work w;                                      // the workspace layout is a property of the whole batch
     rc = check_vp8_work(n, fh, d_work, work_bytes, w); if (rc) return rc;
-    return launch_finish(n, fh, fd, static_cast<const uint8_t*>(d_work), w, 0, d_y, d_u, d_v, d_alpha, d_argb, hipStream_t(stream));
+    return launch_finish(count, fh + first, fd + first, static_cast<const uint8_t*>(d_work), w, 0, d_y, d_u, d_v, d_alpha, d_argb, hipStream_t(stream));
+}
+
+int wp_vp8_finish_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const void* d_work, size_t work_bytes,
+                      uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, const uint8_t* d_alpha, uint8_t* d_argb, void* stream) {
+    return wp_vp8_finish_range_dev(n, fh, fd, 0, n, d_work, work_bytes, d_y, d_u, d_v, d_alpha, d_argb, stream);
 }
 
 int wp_yuv420_to_argb_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint8_t* d_y, const uint8_t* d_u,

@@ -47,19 +47,30 @@ class DeviceLossyBatch:
     def _alpha(self):
         return self.alpha.data_ptr() if self.alpha is not None else None
 
-    def recon(self, planes=True):
+    def second_workspace(self):
+        """A second workspace of the same size (LossyPipeline alternates between the two)."""
+        if getattr(self, "work2", None) is None:
+            self.work2 = torch.empty(max(self.work_bytes, 256), dtype=torch.uint8, device=self.device)
+        return self.work2
+
+    def recon(self, planes=True, work=None):
         """Reconstruction into the tiled workspace; planes=True also writes the unfiltered row-major planes."""
+        work = self.work if work is None else work
         check(lib().wp_vp8_recon_dev(self.b.n, self.b.desc, self.frames.data_ptr(), self.mb.data_ptr(), self.coeff.data_ptr(),
-                                     self.work.data_ptr(), self.work_bytes, *self._planes(planes), self._stream()))
+                                     work.data_ptr(), self.work_bytes, *self._planes(planes), self._stream()))
 
-    def loopfilter(self, planes=True):
+    def loopfilter(self, planes=True, work=None):
         """planes=True: filter the row-major planes in place; planes=False: workspace R tiles -> S tiles."""
+        work = self.work if work is None else work
         check(lib().wp_vp8_loopfilter_dev(self.b.n, self.b.desc, self.frames.data_ptr(), self.filt.data_ptr(),
-                                          self.work.data_ptr(), self.work_bytes, *self._planes(planes), self._stream()))
+                                          work.data_ptr(), self.work_bytes, *self._planes(planes), self._stream()))
 
-    def finish(self, planes=True, argb=True):
-        check(lib().wp_vp8_finish_dev(self.b.n, self.b.desc, self.frames.data_ptr(), self.work.data_ptr(), self.work_bytes,
-                                      *self._planes(planes), self._alpha(), self.argb.data_ptr() if argb else None, self._stream()))
+    def finish(self, planes=True, argb=True, work=None, first=0, count=None):
+        """Finishing pass of frames [first, first + count) (default: all)."""
+        work = self.work if work is None else work
+        count = self.b.n - first if count is None else count
+        check(lib().wp_vp8_finish_range_dev(self.b.n, self.b.desc, self.frames.data_ptr(), first, count, work.data_ptr(), self.work_bytes,
+                                            *self._planes(planes), self._alpha(), self.argb.data_ptr() if argb else None, self._stream()))
 
     def convert(self):
         check(lib().wp_yuv420_to_argb_dev(self.b.n, self.b.desc, self.frames.data_ptr(), self.y.data_ptr(), self.u.data_ptr(),
@@ -85,78 +96,137 @@ class DeviceLossyBatch:
 
 
 class LossyPipeline:
-    """Software pipeline over successive device batches: reconstruction and loop filter are enqueued on one HIP stream,
-    the finishing pass on a second one, so the memory-bound finishing pass of step k runs while the issue-bound
-    reconstruction of step k+1 has already started (measured on 1024 x 1080p: 9.4 -> 8.2 ms per step).
+    """Software pipeline over successive device batches, in two phases per step on two HIP streams:
 
-    Hazards on the shared workspace, kept by events: the loop filter of step k+1 rewrites the S tiles the finishing pass
-    of step k reads, so it waits for that pass; frames without loop filter are read by the finishing pass from the R
-    tiles, so for a batch holding such frames the next reconstruction waits as well (no overlap then).  Outputs (planes,
-    ARGB) of a batch are complete once `drain()` has returned or the event `submit()` returns has been waited for.
+        phase 1:  reconstruction of step k     |  finishing pass of step k-1, frames [0, split)
+        phase 2:  loop filter of step k        |  finishing pass of step k-1, frames [split, n)
+
+    The finishing pass is bound by memory bandwidth, reconstruction and the loop filter by instruction issue: side by side
+    they fill each other's gaps.  The finishing pass is split because next to reconstruction alone the pair is already at
+    the bandwidth the device delivers (23 GB in 5.0 ms), while the loop filter that followed ran with the memory system
+    half idle.  The two kernels of a phase are released together, after both kernels of the phase before have finished:
+    a persistent kernel (reconstruction, loop filter) that starts while a streaming kernel holds the GPU gets its
+    workgroups placed piecemeal and runs far slower (tools/overlap_delay.py).
+
+    Steps alternate between two workspaces (`DeviceLossyBatch.second_workspace`), so the kernels of step k never touch the
+    tiles the finishing pass of step k-1 reads.  The finishing pass of a step is enqueued by the NEXT `submit()` (or by
+    `drain()`): `submit()` returns the event of the previous step's outputs (None for the first), `drain()` completes
+    everything.
 
     Both streams have the default priority, on purpose: with a high-priority finishing stream the pipeline was seen to
     hang once many streams existed in the process (a queue whose barrier packet waits for the other stream's kernel can
     starve that stream when the two share a hardware pipe).  At most `max_in_flight` steps are queued ahead of the GPU."""
 
-    def __init__(self, device="cuda:0", max_in_flight=3):
+    def __init__(self, device="cuda:0", max_in_flight=3, split=0.6, finish_delay_us=40):
         self.device = torch.device(device)
         self.s_main = torch.cuda.Stream(self.device)
         self.s_finish = torch.cuda.Stream(self.device)
         self.max_in_flight = max_in_flight
+        self.split = split
+        self.finish_delay_cycles = int(finish_delay_us * 2100)     # torch.cuda._sleep counts clock cycles (~2.1 GHz under load)
         self._queued = []               # events of the steps not yet known to be complete, oldest first
-        self._prev_finish = None        # event of the most recent finishing pass
-        self._last_finish = {}          # id(batch) -> event of its last finishing pass
+        self._pending = None            # (db, work, planes, argb, filtered event, timing list) of the step whose finishing pass is not enqueued yet
+        self._phase2_done = None        # event: the most recent second-half finishing pass
+        self._k = 0
         cur = torch.cuda.current_stream(self.device)
         self.s_main.wait_stream(cur)
         self.s_finish.wait_stream(cur)
 
+    @staticmethod
+    def _mark(stream, timing):
+        if timing is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream)
+        return e
+
+    def _let_persistent_kernel_start_first(self):
+        # Both kernels of a phase become runnable at the same moment; the one whose stream saw the phase before end last is
+        # dispatched first.  If that is the streaming finishing pass, the persistent kernel beside it finds the GPU
+        # occupied and runs up to twice as long, so the finishing pass is held back by a few tens of microseconds.
+        if self.finish_delay_cycles > 0:
+            torch.cuda._sleep(self.finish_delay_cycles)
+
+    def _event(self, stream):
+        e = torch.cuda.Event()
+        e.record(stream)
+        return e
+
     def submit(self, db: "DeviceLossyBatch", planes=True, argb=True, timing=None):
-        """Enqueues one step.  `timing`: a list that receives (recon start, recon end, filter start, filter end, finish
-        start, finish end) timing events recorded on the stream each kernel is launched on."""
-        def mark(stream):
-            if timing is None:
-                return None
-            e = torch.cuda.Event(enable_timing=True)
-            e.record(stream)
-            return e
+        """Enqueues reconstruction and loop filter of one step and, beside them, the finishing pass of the step before.
+        `timing`: a list that receives (recon start, recon end, filter start, filter end, finish start, finish end)
+        timing events of THIS step once its finishing pass has been enqueued (by the next submit() or drain())."""
         while len(self._queued) >= self.max_in_flight:
             self._queued.pop(0).synchronize()
-        fin = self._last_finish.get(id(db))
-        unfiltered = db.has_unfiltered
+        work = db.work if (self._k & 1) == 0 else db.second_workspace()
+        self._k += 1
+        prev = self._pending
+        marks = {}
+        # ---- phase 1 ----
         with torch.cuda.stream(self.s_main):
-            if fin is not None and unfiltered:
-                self.s_main.wait_event(fin)
-            r0 = mark(self.s_main)
-            db.recon(planes=False)
-            r1 = mark(self.s_main)
-            # The loop filter waits for the previous finishing pass whichever batch that belonged to: on the same batch it
-            # rewrites the S tiles that pass reads, and in any case a persistent kernel that starts while the streaming
-            # pass holds the GPU gets its workgroups placed piecemeal and runs far slower (tools/overlap_delay.py).
-            if self._prev_finish is not None:
-                self.s_main.wait_event(self._prev_finish)
-            f0 = mark(self.s_main)
-            db.loopfilter(planes=False)
-            f1 = mark(self.s_main)
-            filtered = torch.cuda.Event()
-            filtered.record(self.s_main)
+            if self._phase2_done is not None:
+                self.s_main.wait_event(self._phase2_done)       # the GPU is empty when the pair starts
+            marks["r0"] = self._mark(self.s_main, timing)
+            db.recon(planes=False, work=work)
+            marks["r1"] = self._mark(self.s_main, timing)
+            recon_done = self._event(self.s_main)
+        half_a = None
+        if prev is not None:
+            pdb, pwork, pplanes, pargb, pfiltered, ptiming, pmarks = prev
+            n_a = min(pdb.b.n, max(0, int(round(pdb.b.n * self.split))))
+            with torch.cuda.stream(self.s_finish):
+                self.s_finish.wait_event(pfiltered)
+                self._let_persistent_kernel_start_first()
+                pmarks["c0"] = self._mark(self.s_finish, ptiming)
+                pdb.finish(pplanes, pargb, work=pwork, first=0, count=n_a)
+                pmarks["ca"] = self._mark(self.s_finish, ptiming)
+                half_a = self._event(self.s_finish)
+        # ---- phase 2 ----
+        with torch.cuda.stream(self.s_main):
+            if half_a is not None:
+                self.s_main.wait_event(half_a)
+            marks["f0"] = self._mark(self.s_main, timing)
+            db.loopfilter(planes=False, work=work)
+            marks["f1"] = self._mark(self.s_main, timing)
+            filtered = self._event(self.s_main)
+        done_prev = None
+        if prev is not None:
+            with torch.cuda.stream(self.s_finish):
+                self.s_finish.wait_event(recon_done)
+                self._let_persistent_kernel_start_first()
+                pmarks["cb"] = self._mark(self.s_finish, ptiming)
+                pdb.finish(pplanes, pargb, work=pwork, first=n_a, count=pdb.b.n - n_a)
+                pmarks["c1"] = self._mark(self.s_finish, ptiming)
+                done_prev = self._event(self.s_finish)
+            self._phase2_done = done_prev
+            self._queued.append(done_prev)
+            if ptiming is not None:
+                ptiming.append(pmarks)
+        self._pending = (db, work, planes, argb, filtered, timing, marks)
+        return done_prev
+
+    def flush(self):
+        """Enqueues the finishing pass of the last submitted step (nothing left to overlap it with)."""
+        if self._pending is None:
+            return None
+        pdb, pwork, pplanes, pargb, pfiltered, ptiming, pmarks = self._pending
+        self._pending = None
         with torch.cuda.stream(self.s_finish):
-            self.s_finish.wait_event(filtered)
-            c0 = mark(self.s_finish)
-            db.finish(planes, argb)
-            c1 = mark(self.s_finish)
-            done = torch.cuda.Event()
-            done.record(self.s_finish)
-        if timing is not None:
-            timing.append((r0, r1, f0, f1, c0, c1))
-        self._last_finish[id(db)] = done
-        self._prev_finish = done
+            self.s_finish.wait_event(pfiltered)
+            pmarks["c0"] = self._mark(self.s_finish, ptiming)
+            pdb.finish(pplanes, pargb, work=pwork)
+            pmarks["c1"] = self._mark(self.s_finish, ptiming)
+            done = self._event(self.s_finish)
+        if ptiming is not None:
+            ptiming.append(pmarks)
+        self._phase2_done = done
         self._queued.append(done)
         return done
 
     def drain(self):
+        self.flush()
         cur = torch.cuda.current_stream(self.device)
         cur.wait_stream(self.s_main)
         cur.wait_stream(self.s_finish)
-        self._last_finish.clear()
         self._queued.clear()
-        self._prev_finish = None
+        self._phase2_done = None
