@@ -104,6 +104,8 @@ def main():
 
     from webp_amd.device import LossyPipeline
     pipe = None if args.serial else LossyPipeline(device, split=args.split, finish_delay_us=args.finish_delay_us)
+    if pipe is not None:
+        db.second_workspace()                        # allocated here, not by the first odd step inside the timed region
 
     marks = []                                       # per step: timing events around each kernel, on its launch stream
 
