@@ -42,8 +42,23 @@ __device__ __forceinline__ uint4 convert_row4(uint32_t y4, const ChromaTerms& t0
     return make_uint4(convert_px<FIX>(int(y4 & 0xff), t0, a4 & 0xff), convert_px<FIX>(int((y4 >> 8) & 0xff), t0, (a4 >> 8) & 0xff),
                       convert_px<FIX>(int((y4 >> 16) & 0xff), t1, (a4 >> 16) & 0xff), convert_px<FIX>(int(y4 >> 24), t1, a4 >> 24));
 }
+// The same without the tie correction, in packed 16-bit arithmetic: pixels (0, 2) and (1, 3) of the row share the term
+// pair (t0, t1), so each channel is two packed adds and a saturating pack (clip_pack: 0..255, bytes in pixel order),
+// and a 4x4 byte transpose turns the four channel dwords into four A,R,G,B pixels: 26 instructions for four pixels
+// where the scalar form above takes about 44.
+__device__ __forceinline__ uint4 convert_row4_packed(uint32_t y4, const ChromaTerms& t0, const ChromaTerms& t1, uint32_t a4) {
+    const short2_t y02 = as_s2(y4 & 0x00ff00ffu), y13 = as_s2((y4 >> 8) & 0x00ff00ffu);
+    const short2_t tr = as_s2(__builtin_amdgcn_perm(uint32_t(t1.r), uint32_t(t0.r), 0x05040100u));      // (t0, t1) as an int16 pair
+    const short2_t tg = as_s2(__builtin_amdgcn_perm(uint32_t(t1.g), uint32_t(t0.g), 0x05040100u));
+    const short2_t tb = as_s2(__builtin_amdgcn_perm(uint32_t(t1.b), uint32_t(t0.b), 0x05040100u));
+    const uint32_t r4 = clip_pack(y02 + tr, y13 + tr), g4 = clip_pack(y02 + tg, y13 + tg), b4 = clip_pack(y02 + tb, y13 + tb);
+    const uint32_t ar_lo = __builtin_amdgcn_perm(r4, a4, 0x05010400u), ar_hi = __builtin_amdgcn_perm(r4, a4, 0x07030602u);   // A0 R0 A1 R1 | A2 R2 A3 R3
+    const uint32_t gb_lo = __builtin_amdgcn_perm(b4, g4, 0x05010400u), gb_hi = __builtin_amdgcn_perm(b4, g4, 0x07030602u);   // G0 B0 G1 B1 | G2 B2 G3 B3
+    return make_uint4(__builtin_amdgcn_perm(gb_lo, ar_lo, 0x05040100u), __builtin_amdgcn_perm(gb_lo, ar_lo, 0x07060302u),
+                      __builtin_amdgcn_perm(gb_hi, ar_hi, 0x05040100u), __builtin_amdgcn_perm(gb_hi, ar_hi, 0x07060302u));
+}
 __device__ __forceinline__ uint4 convert_row4(uint32_t y4, const ChromaTerms& t0, const ChromaTerms& t1, uint32_t a4, bool any_tie) {
-    return any_tie ? convert_row4<true>(y4, t0, t1, a4) : convert_row4<false>(y4, t0, t1, a4);
+    return any_tie ? convert_row4<true>(y4, t0, t1, a4) : convert_row4_packed(y4, t0, t1, a4);
 }
 
 // luma dword + two chroma samples each (u2, v2: two bytes) -> 16 bytes of A,R,G,B
