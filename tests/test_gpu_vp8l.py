@@ -114,6 +114,48 @@ def test_full_chain_with_swizzle():
     assert np.array_equal(g, e)
 
 
+@pytest.mark.parametrize("swizzle", [0, 1])
+@pytest.mark.parametrize("order", [(1, 0), (0, 2), (2, 1, 0), (1, 2, 0), (0, 1, 2), (2, 0), (0, 1), (2, 0, 1)])
+def test_transform_orders_and_fused_passes(order, swizzle):
+    """The kernels fold a cross-colour undone right before a predictor, a subtract-green undone right after it and the
+    final copy / rotation into the predictor pass (and the final copy into a last colour-indexing pass); every other
+    order takes one pass per transform.  Transform lists in orders no encoder emits, 150 rows (three 64-row bands: the
+    band hand-over reads raw predictor output back), both byte orders."""
+    from oracle import oracle
+    rng = np.random.default_rng(100 + sum(order) + 7 * len(order) + swizzle)
+    w, h = 77, 150
+    pix = rng.integers(0, 256, 4 * w * h, dtype=np.uint8)
+    data = {0: _tiles(rng, w, h, 3, list(range(14))), 1: _tiles(rng, w, h, 2), 2: np.zeros(0, np.uint8)}
+    bits = {0: 3, 1: 2, 2: 0}
+    chain = [(t, bits[t], w, data[t]) for t in order]                 # bitstream order
+    e = pix
+    for t in reversed(order):                                         # undone last-read-first (Vp8LDecoder.hx:395-401)
+        if t == 0: e = oracle.inverse_predictor(w, bits[0], data[0], e, h)
+        elif t == 1: e = oracle.inverse_cross_color(w, bits[1], data[1], e, h)
+        else: e = oracle.inverse_subtract_green(e)
+    if swizzle:
+        e = np.ascontiguousarray(e.reshape(-1, 4)[:, [3, 0, 1, 2]]).reshape(-1)
+    g = _run_chain([dict(width=w, height=h, coded_width=w, pix=pix, transforms=chain)], swizzle=swizzle)[0]
+    assert np.array_equal(g, e)
+
+
+@pytest.mark.parametrize("swizzle", [0, 1])
+def test_palette_after_predictor(swizzle):
+    """Colour indexing without pixel packing (bits 0) as the last transform undone, after a predictor on the index
+    image (libwebp's palette + spatial mode): the indexing pass writes the result slab itself."""
+    from oracle import oracle
+    rng = np.random.default_rng(9 + swizzle)
+    w, h = 45, 70
+    pix = rng.integers(0, 256, 4 * w * h, dtype=np.uint8)
+    pal = rng.integers(0, 256, 4 * 256, dtype=np.uint8)
+    tp = _tiles(rng, w, h, 2, list(range(14)))
+    e = oracle.inverse_color_indexing(w, 0, pal, oracle.inverse_predictor(w, 2, tp, pix, h), h)
+    if swizzle:
+        e = np.ascontiguousarray(e.reshape(-1, 4)[:, [3, 0, 1, 2]]).reshape(-1)
+    g = _run_chain([dict(width=w, height=h, coded_width=w, pix=pix, transforms=[(3, 0, w, pal), (0, 2, w, tp)])], swizzle=swizzle)[0]
+    assert np.array_equal(g, e)
+
+
 def test_green_only_output_is_the_green_channel():
     """WP_SWIZZLE_GREEN: the last pass keeps what readAlpha keeps of a VP8L-coded ALPH image (WebPDecoder.hx:330-336).
     Sizes cover every pixel count mod 4 (the kernel packs four pixels per store) and a colour-indexed image, whose last

@@ -39,12 +39,33 @@ __device__ __forceinline__ uint32_t add_px(uint32_t a, uint32_t b) {
 // per-byte floor((a + b) / 2)  (Transform.hx:283-285 avg2)
 __device__ __forceinline__ uint32_t avg_px(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0u); }   // v_lerp_u8: (a + b + 0) >> 1 per byte
 
+// ---------------------------------------------------------------- pass fusion
+// Each pass over an image costs 8 bytes of HBM traffic per pixel, so the passes libwebp's streams need are folded into
+// the kernels next to them; every kernel decides per frame, from the transform list alone, with the same predicates:
+//   * a cross-colour transform undone directly before a predictor is applied by the predictor kernel as it loads;
+//   * the frame's final pixels (R,G,B,A or rotated to A,R,G,B) are written into the result slab by the predictor kernel
+//     when the predictor is the last transform undone, or the last but a subtract-green (applied on the way out), and by
+//     the colour-indexing kernel when that is the last; the finishing pass then skips the frame.
+// Anything else (and green-only output) takes the general one-pass-per-transform route.
+enum OutputWriter { kOutFinish = 0, kOutPredictor = 1, kOutPredictorSG = 2, kOutIndexing = 3 };
+__device__ __forceinline__ int output_writer(const wp_vp8l_frame& fr, int swizzle) {
+    if (swizzle == WP_SWIZZLE_GREEN || fr.n_transforms == 0) return kOutFinish;
+    if (fr.t[0].type == 0) return kOutPredictor;
+    if (fr.t[0].type == 2 && fr.n_transforms >= 2 && fr.t[1].type == 0) return kOutPredictorSG;
+    if (fr.t[0].type == 3) return kOutIndexing;
+    return kOutFinish;
+}
+// is the cross-colour transform at index idx undone by the predictor kernel (the transform undone right after it)?
+__device__ __forceinline__ bool cross_color_fused(const wp_vp8l_frame& fr, int idx) { return idx >= 1 && fr.t[idx - 1].type == 0; }
+__device__ __forceinline__ uint32_t swizzled(uint32_t v, int swizzle) { return swizzle == WP_SWIZZLE_ARGB ? ((v << 8) | (v >> 24)) : v; }
+
 // ---------------------------------------------------------------- streaming transforms
 __global__ __launch_bounds__(256)
-void vp8l_subtract_green_kernel(const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp) {
+void vp8l_subtract_green_kernel(const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp, int swizzle) {
     const wp_vp8l_frame& fr = frames[blockIdx.y];
     const int idx = fr.n_transforms - 1 - pass;
     if (idx < 0 || fr.t[idx].type != 2) return;
+    if (idx == 0 && output_writer(fr, swizzle) == kOutPredictorSG) return;       // applied by the predictor kernel
     const Loc loc = locate(fr, idx);
     uint32_t* p = reinterpret_cast<uint32_t*>(loc.in_tmp ? tmp + fr.tmp_off : pix + fr.pix_off);
     const long long total = (long long)loc.width * fr.height;          // the reference walks the whole buffer (:227)
@@ -56,12 +77,21 @@ void vp8l_subtract_green_kernel(const wp_vp8l_frame* __restrict__ frames, int pa
 }
 
 __device__ __forceinline__ int s8(uint32_t v) { return int(int8_t(v & 0xff)); }
+// one pixel of inverseCrossColor (Transform.hx:202-218); t = the tile's three multipliers
+__device__ __forceinline__ uint32_t cross_color_px(uint32_t v, uint32_t t) {
+    const int r2b = s8(t), g2b = s8(t >> 8), g2r = s8(t >> 16);       // Transform.hx:202-204
+    const int g = s8(v >> 8);
+    uint32_t red = (v & 0xff) + (uint32_t(g2r * g) >> 5);              // unsigned >>> 5, low 8 bits kept (Q10)
+    uint32_t blue = ((v >> 16) & 0xff) + (uint32_t(g2b * g) >> 5);
+    blue = (blue & 0xff) + (uint32_t(r2b * s8(red)) >> 5);
+    return (v & 0xff00ff00u) | (red & 0xff) | ((blue & 0xff) << 16);
+}
 
 __global__ __launch_bounds__(256)
 void vp8l_cross_color_kernel(const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp, const uint8_t* __restrict__ aux) {
     const wp_vp8l_frame& fr = frames[blockIdx.y];
     const int idx = fr.n_transforms - 1 - pass;
-    if (idx < 0 || fr.t[idx].type != 1) return;
+    if (idx < 0 || fr.t[idx].type != 1 || cross_color_fused(fr, idx)) return;
     const Loc loc = locate(fr, idx);
     uint32_t* p = reinterpret_cast<uint32_t*>(loc.in_tmp ? tmp + fr.tmp_off : pix + fr.pix_off);
     const int w = fr.t[idx].old_width, bits = fr.t[idx].bits;
@@ -70,19 +100,13 @@ void vp8l_cross_color_kernel(const wp_vp8l_frame* __restrict__ frames, int pass,
     const long long total = (long long)w * fr.height;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int y = int(i / w), x = int(i - (long long)y * w);
-        const uint32_t t = tiles[(y >> bits) * tpr + (x >> bits)];
-        const int r2b = s8(t), g2b = s8(t >> 8), g2r = s8(t >> 16);       // Transform.hx:202-204
-        const uint32_t v = p[i];
-        const int g = s8(v >> 8);
-        uint32_t red = (v & 0xff) + (uint32_t(g2r * g) >> 5);              // unsigned >>> 5, low 8 bits kept (Q10)
-        uint32_t blue = ((v >> 16) & 0xff) + (uint32_t(g2b * g) >> 5);
-        blue = (blue & 0xff) + (uint32_t(r2b * s8(red)) >> 5);
-        p[i] = (v & 0xff00ff00u) | (red & 0xff) | ((blue & 0xff) << 16);
+        p[i] = cross_color_px(p[i], tiles[(y >> bits) * tpr + (x >> bits)]);
     }
 }
 
 __global__ __launch_bounds__(256)
-void vp8l_color_indexing_kernel(const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp, const uint8_t* __restrict__ aux) {
+void vp8l_color_indexing_kernel(const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp, const uint8_t* __restrict__ aux,
+                                uint8_t* out, int swizzle) {
     const wp_vp8l_frame& fr = frames[blockIdx.y];
     const int idx = fr.n_transforms - 1 - pass;
     if (idx < 0 || fr.t[idx].type != 3) return;
@@ -90,14 +114,17 @@ void vp8l_color_indexing_kernel(const wp_vp8l_frame* __restrict__ frames, int pa
     const uint32_t* src = reinterpret_cast<const uint32_t*>(loc.in_tmp ? tmp + fr.tmp_off : pix + fr.pix_off);
     const int w = fr.t[idx].old_width, bits = fr.t[idx].bits;
     const uint32_t* palette = reinterpret_cast<const uint32_t*>(aux + fr.t[idx].data_off);
+    const bool final_out = idx == 0 && output_writer(fr, swizzle) == kOutIndexing;      // the last transform undone: straight into the result slab
+    const int sw = final_out ? swizzle : WP_SWIZZLE_NONE;
     if (bits == 0) {                                                        // in place, whole buffer (:237-248)
         uint32_t* p = const_cast<uint32_t*>(src);
+        uint32_t* q = final_out ? reinterpret_cast<uint32_t*>(out + fr.out_off) : p;
         const long long total = (long long)loc.width * fr.height;
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
-            p[i] = palette[(p[i] >> 8) & 0xff];
+            q[i] = swizzled(palette[(p[i] >> 8) & 0xff], sw);
         return;
     }
-    uint32_t* dst = reinterpret_cast<uint32_t*>(tmp + fr.tmp_off);           // new 4*oldWidth*h buffer (:261)
+    uint32_t* dst = reinterpret_cast<uint32_t*>(final_out ? out + fr.out_off : tmp + fr.tmp_off);     // new 4*oldWidth*h buffer (:261)
     const int pw = loc.width;                                                // packed row length = nTiles(oldWidth, bits)
     const int bpp = 8 >> bits, xmask = (1 << bits) - 1;
     const uint32_t vmask = (1u << bpp) - 1u;
@@ -105,7 +132,7 @@ void vp8l_color_indexing_kernel(const wp_vp8l_frame* __restrict__ frames, int pa
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int y = int(i / w), x = int(i - (long long)y * w);
         const uint32_t g = (src[(long long)y * pw + (x >> bits)] >> 8) & 0xff;
-        dst[i] = palette[(g >> ((x & xmask) * bpp)) & vmask];
+        dst[i] = swizzled(palette[(g >> ((x & xmask) * bpp)) & vmask], sw);
     }
 }
 
@@ -113,6 +140,7 @@ void vp8l_color_indexing_kernel(const wp_vp8l_frame* __restrict__ frames, int pa
 __global__ __launch_bounds__(256)
 void vp8l_finish_kernel(const wp_vp8l_frame* __restrict__ frames, const uint8_t* pix, const uint8_t* tmp, uint8_t* out, int swizzle) {
     const wp_vp8l_frame& fr = frames[blockIdx.y];
+    if (output_writer(fr, swizzle) != kOutFinish) return;                    // a transform kernel wrote this frame's result already
     const Loc loc = locate(fr, -1);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(loc.in_tmp ? tmp + fr.tmp_off : pix + fr.pix_off);
     const long long total = (long long)fr.width * fr.height;
@@ -135,7 +163,7 @@ void vp8l_finish_kernel(const wp_vp8l_frame* __restrict__ frames, const uint8_t*
     uint32_t* dst = reinterpret_cast<uint32_t*>(out + fr.out_off);
     for (long long i = first; i < total; i += stride) {
         const uint32_t v = src[i];
-        dst[i] = swizzle == WP_SWIZZLE_ARGB ? ((v << 8) | (v >> 24)) : v;
+        dst[i] = swizzled(v, swizzle);
     }
 }
 
@@ -188,7 +216,7 @@ constexpr int kPC = WP_PRED_CHUNK;
 
 __global__ __launch_bounds__(kWavesPerWG * kWave)
 void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp,
-                           const uint8_t* __restrict__ aux) {
+                           const uint8_t* __restrict__ aux, uint8_t* out, int swizzle) {
     __shared__ uint32_t progress[kWavesPerWG];
     const int wave = threadIdx.x >> 6;
     const int r = threadIdx.x & 63;                 // row within the band
@@ -206,6 +234,15 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
         if (w == 0 || h == 0) continue;
         const int tpr = n_tiles(w, bits);
         const uint8_t* tiles = aux + fr.t[idx].data_off;
+        // fused neighbours (see "pass fusion" above): cross-colour on the way in, subtract-green + rotation on the way out
+        const bool cc = idx + 1 < fr.n_transforms && fr.t[idx + 1].type == 1;
+        const int cc_bits = cc ? fr.t[idx + 1].bits : 0;
+        const int cc_tpr = n_tiles(w, cc_bits);
+        const uint32_t* cc_tiles = reinterpret_cast<const uint32_t*>(aux + (cc ? fr.t[idx + 1].data_off : 0));
+        const int ow = output_writer(fr, swizzle);
+        const bool to_out = (ow == kOutPredictor && idx == 0) || (ow == kOutPredictorSG && idx == 1);
+        const bool sg_out = to_out && ow == kOutPredictorSG;
+        uint32_t* const obase = reinterpret_cast<uint32_t*>(out + fr.out_off);
         const int n_bands = (h + kPredRows - 1) / kPredRows;
         const int n_chunks = (w + kPC - 1) / kPC;
 
@@ -221,6 +258,10 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
             uint32_t* row = base + (long long)(row_ok ? y : 0) * w;
             const uint32_t* above_row = base + (long long)(y > 0 ? y - 1 : 0) * w;
             const uint8_t* tile_row = tiles + 4 * ((row_ok ? y : 0) >> bits) * tpr;
+            const uint32_t* cc_row = cc_tiles + ((row_ok ? y : 0) >> cc_bits) * cc_tpr;
+            uint32_t* orow = obase + (long long)(row_ok ? y : 0) * w;
+            // the next band reads this band's last row back (unrotated, before subtract-green): that row is also stored in place
+            const bool keep_raw = !to_out || (has_below && r == kPredRows - 1);
 
             uint32_t P1[kPC], T4[kPC], Tn[kPC];     // my previous chunk's outputs (what the row below fetches); row above: this chunk, next chunk
 #pragma unroll
@@ -257,7 +298,7 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                 }
                 if (act) {
                     const int x0 = kPC * k;
-                    uint32_t in[kPC], out[kPC];
+                    uint32_t in[kPC], res[kPC];
                     if (x0 + kPC <= w) {
 #pragma unroll
                         for (int g4 = 0; g4 < kPC / 4; ++g4) {
@@ -268,6 +309,14 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                     } else {
 #pragma unroll
                         for (int j = 0; j < kPC; ++j) in[j] = (x0 + j < w) ? row[x0 + j] : 0u;
+                    }
+                    if (cc) {                // inverseCrossColor of the pixels just loaded (a 4-pixel group never straddles a tile: bits >= 2)
+#pragma unroll
+                        for (int g4 = 0; g4 < kPC / 4; ++g4) {
+                            const uint32_t t = cc_row[min(x0 + 4 * g4, w - 1) >> cc_bits];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) in[4 * g4 + j] = cross_color_px(in[4 * g4 + j], t);
+                        }
                     }
                     int tile_mode = 0;
 #pragma unroll
@@ -284,25 +333,47 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                             if (x == w - 1) TR = first_px;                        // linear addressing: top+4 is the row's own first pixel
                             pred = predict_px(tile_mode, Lpx, T4[j], TL, TR);
                         }
-                        out[j] = add_px(in[j], pred);
-                        if (x < w) Lpx = out[j];
-                        if (x == 0) first_px = out[j];
+                        res[j] = add_px(in[j], pred);
+                        if (x < w) Lpx = res[j];
+                        if (x == 0) first_px = res[j];
                     }
-                    if (x0 + kPC <= w) {
+                    if (keep_raw) {
+                        if (x0 + kPC <= w) {
 #pragma unroll
-                        for (int g4 = 0; g4 < kPC / 4; ++g4) {
-                            Px4 v;
+                            for (int g4 = 0; g4 < kPC / 4; ++g4) {
+                                Px4 v;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v.v[j] = out[4 * g4 + j];
-                            *reinterpret_cast<Px4*>(row + x0 + 4 * g4) = v;
+                                for (int j = 0; j < 4; ++j) v.v[j] = res[4 * g4 + j];
+                                *reinterpret_cast<Px4*>(row + x0 + 4 * g4) = v;
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < kPC; ++j) if (x0 + j < w) row[x0 + j] = res[j];
                         }
-                    } else {
+                    }
+                    if (to_out) {            // final pixels: R += G, B += G if a subtract-green follows, then the byte order asked for
+                        uint32_t fin[kPC];
 #pragma unroll
-                        for (int j = 0; j < kPC; ++j) if (x0 + j < w) row[x0 + j] = out[j];
+                        for (int j = 0; j < kPC; ++j) {
+                            const uint32_t g = (res[j] >> 8) & 0xff;
+                            fin[j] = swizzled(sg_out ? add_px(res[j], g | (g << 16)) : res[j], swizzle);
+                        }
+                        if (x0 + kPC <= w) {
+#pragma unroll
+                            for (int g4 = 0; g4 < kPC / 4; ++g4) {
+                                Px4 v;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v.v[j] = fin[4 * g4 + j];
+                                *reinterpret_cast<Px4*>(orow + x0 + 4 * g4) = v;
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < kPC; ++j) if (x0 + j < w) orow[x0 + j] = fin[j];
+                        }
                     }
                     TLfirst = T4[kPC - 1];
 #pragma unroll
-                    for (int j = 0; j < kPC; ++j) P1[j] = out[j];
+                    for (int j = 0; j < kPC; ++j) P1[j] = res[j];
                 }
                 if (has_below) {
                     const int k_last = c - 2 * (kPredRows - 1);
@@ -445,10 +516,10 @@ extern "C" int wpk_launch_vp8l(int n, const wp_vp8l_frame* fh, const wp_vp8l_fra
             }
             if (have[0])
                 hipLaunchKernelGGL(vp8l_predictor_kernel, dim3(std::min(cnt, 1024)), dim3(kWavesPerWG * kWave), 0, stream,
-                                   cnt, fdc, pass, d_pix, d_tmp, d_aux);
+                                   cnt, fdc, pass, d_pix, d_tmp, d_aux, d_out, swizzle);
             if (have[1]) hipLaunchKernelGGL(vp8l_cross_color_kernel, dim3(gx, cnt), dim3(256), 0, stream, fdc, pass, d_pix, d_tmp, d_aux);
-            if (have[2]) hipLaunchKernelGGL(vp8l_subtract_green_kernel, dim3(gx, cnt), dim3(256), 0, stream, fdc, pass, d_pix, d_tmp);
-            if (have[3]) hipLaunchKernelGGL(vp8l_color_indexing_kernel, dim3(gx, cnt), dim3(256), 0, stream, fdc, pass, d_pix, d_tmp, d_aux);
+            if (have[2]) hipLaunchKernelGGL(vp8l_subtract_green_kernel, dim3(gx, cnt), dim3(256), 0, stream, fdc, pass, d_pix, d_tmp, swizzle);
+            if (have[3]) hipLaunchKernelGGL(vp8l_color_indexing_kernel, dim3(gx, cnt), dim3(256), 0, stream, fdc, pass, d_pix, d_tmp, d_aux, d_out, swizzle);
         }
         hipLaunchKernelGGL(vp8l_finish_kernel, dim3(gx, cnt), dim3(256), 0, stream, fdc, d_pix, d_tmp, d_out, swizzle);
     }
