@@ -76,6 +76,12 @@ class LossyStream:
             return t, used
 
         names = ("argb", "y", "u", "v") if self.planes else ("argb",)
+        try:
+            return self._decode_chunks(job, chunks, n, names, items, outs, out_slab)
+        finally:
+            job.close()                         # also on an error: the parser threads stop and the parsed files are released
+
+    def _decode_chunks(self, job, chunks, n, names, items, outs, out_slab):
         for k in range(len(chunks)):
             files = job.take(min(n, (k + 1) * self.chunk))
             frames = []
@@ -126,7 +132,6 @@ class LossyStream:
                     it.update(y_off=base["y"] + d.y_off, u_off=base["u"] + d.u_off, v_off=base["v"] + d.v_off)
                 items.append(it)
             slot.keep = (b, files)              # host objects stay alive until the slot is reused
-        job.close()
         for s in self.slots:
             if s.done is not None:
                 s.done.synchronize()
