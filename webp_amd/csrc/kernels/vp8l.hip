@@ -204,6 +204,12 @@ __device__ __forceinline__ uint32_t predict_px(int mode, uint32_t L, uint32_t T,
 struct __attribute__((aligned(4))) Px4 { uint32_t v[4]; };
 constexpr uint32_t kPredSeqShift = 15;      // progress word = (band sequence << 15) | pixels finished in the band's last row
 constexpr int kPredRows = 64;
+// Wavefronts per workgroup (= bands of one frame that can be in flight).  A band trails the one above by 126 steps and
+// lasts n_chunks + 126, so only about three are ever active; registers held by idle wavefronts cost resident frames.
+#ifndef WP_PRED_WAVES
+#define WP_PRED_WAVES 4
+#endif
+constexpr int kPredWaves = WP_PRED_WAVES;
 // Pixels a lane handles per step.  Every lane walks its own row, so a step touches 64 different rows: with 4 pixels
 // (16 bytes) per row the kernel is bound by the L2 request rate (tools/ubench/row_access.hip: row-strided 16-byte
 // accesses reach 1.1 / 1.7 TB/s for loads / stores, 32-byte ones 3.3 / 1.9 TB/s); with more pixels per step the
@@ -214,13 +220,13 @@ constexpr int kPredRows = 64;
 #endif
 constexpr int kPC = WP_PRED_CHUNK;
 
-__global__ __launch_bounds__(kWavesPerWG * kWave)
+__global__ __launch_bounds__(kPredWaves * kWave)
 void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp,
                            const uint8_t* __restrict__ aux, uint8_t* out, int swizzle) {
-    __shared__ uint32_t progress[kWavesPerWG];
+    __shared__ uint32_t progress[kPredWaves];
     const int wave = threadIdx.x >> 6;
     const int r = threadIdx.x & 63;                 // row within the band
-    if (threadIdx.x < kWavesPerWG) progress[threadIdx.x] = 0;
+    if (threadIdx.x < kPredWaves) progress[threadIdx.x] = 0;
     __syncthreads();
 
     uint32_t seq = 1;
@@ -248,11 +254,11 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
 
         for (int band = 0; band < n_bands; ++band) {
             const uint32_t q = seq + uint32_t(band);
-            if (int(q % kWavesPerWG) != wave) continue;
+            if (int(q % kPredWaves) != wave) continue;
             const int y = band * kPredRows + r;
             const bool row_ok = y < h;
             const bool has_above = band > 0, has_below = band + 1 < n_bands;
-            const int prev_wave = (wave + kWavesPerWG - 1) % kWavesPerWG;
+            const int prev_wave = (wave + kPredWaves - 1) % kPredWaves;
             const int rows_here = min(kPredRows, h - band * kPredRows);
             const int n_steps = n_chunks + 2 * (rows_here - 1);
             uint32_t* row = base + (long long)(row_ok ? y : 0) * w;
@@ -268,6 +274,37 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
             for (int j = 0; j < kPC; ++j) { P1[j] = 0; T4[j] = 0; Tn[j] = 0; }
             uint32_t TLfirst = 0, Lpx = 0, first_px = 0;
             uint32_t avail = 0;                     // pixels of the row above known to be finished (band boundary)
+            uint32_t pending_publish = 0;
+            // A step's own inputs (its 8 pixels, the tile modes of its two 4-pixel groups, the cross-colour multipliers)
+            // depend on nothing the wavefront computes, so they are fetched one step ahead: with two or three bands of a
+            // frame in flight there are too few wavefronts per SIMD to hide a load issued where it is used.
+            uint32_t nx_in[kPC], nx_mode[kPC / 4], nx_cc[kPC / 4];
+#pragma unroll
+            for (int j = 0; j < kPC; ++j) nx_in[j] = 0;
+#pragma unroll
+            for (int g4 = 0; g4 < kPC / 4; ++g4) { nx_mode[g4] = 0; nx_cc[g4] = 0; }
+            auto fetch = [&](int kk) {
+                if (!(row_ok && kk >= 0 && kk < n_chunks)) return;
+                const int xx = kPC * kk;
+                if (xx + kPC <= w) {
+#pragma unroll
+                    for (int g4 = 0; g4 < kPC / 4; ++g4) {
+                        const Px4 v = *reinterpret_cast<const Px4*>(row + xx + 4 * g4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) nx_in[4 * g4 + j] = v.v[j];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kPC; ++j) nx_in[j] = (xx + j < w) ? row[xx + j] : 0u;
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < kPC / 4; ++g4) {
+                    // a 4-pixel group never straddles a tile (bits >= 2); tiles beyond the row's end are never read
+                    nx_mode[g4] = tile_row[4 * (min(xx + 4 * g4, w - 1) >> bits) + 1];
+                    if (cc) nx_cc[g4] = cc_row[min(xx + 4 * g4, w - 1) >> cc_bits];
+                }
+            };
+            fetch(-2 * r);
 
             for (int c = 0; c < n_steps; ++c) {
                 const int k = c - 2 * r;
@@ -296,34 +333,33 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                         }
                     }
                 }
+                // this step's inputs were fetched during the previous step; the next step's are requested now and land
+                // while this chunk is being computed (a lane's first chunk is requested one step before it starts)
+                uint32_t in[kPC], cc_of[kPC / 4];
+                int mode_of[kPC / 4];
+#pragma unroll
+                for (int j = 0; j < kPC; ++j) in[j] = nx_in[j];
+#pragma unroll
+                for (int g4 = 0; g4 < kPC / 4; ++g4) { mode_of[g4] = int(nx_mode[g4] & 15); cc_of[g4] = nx_cc[g4]; }
+                fetch(k + 1);
                 if (act) {
                     const int x0 = kPC * k;
-                    uint32_t in[kPC], res[kPC];
-                    if (x0 + kPC <= w) {
+                    uint32_t res[kPC];
+                    if (cc) {                // inverseCrossColor of the pixels loaded (a 4-pixel group never straddles a tile: bits >= 2)
 #pragma unroll
                         for (int g4 = 0; g4 < kPC / 4; ++g4) {
-                            const Px4 v = *reinterpret_cast<const Px4*>(row + x0 + 4 * g4);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) in[4 * g4 + j] = v.v[j];
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < kPC; ++j) in[j] = (x0 + j < w) ? row[x0 + j] : 0u;
-                    }
-                    if (cc) {                // inverseCrossColor of the pixels just loaded (a 4-pixel group never straddles a tile: bits >= 2)
-#pragma unroll
-                        for (int g4 = 0; g4 < kPC / 4; ++g4) {
-                            const uint32_t t = cc_row[min(x0 + 4 * g4, w - 1) >> cc_bits];
+                            const uint32_t t = cc_of[g4];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) in[4 * g4 + j] = cross_color_px(in[4 * g4 + j], t);
                         }
                     }
+#ifdef WP_PRED_BRANCHY
                     int tile_mode = 0;
 #pragma unroll
                     for (int j = 0; j < kPC; ++j) {
                         const int x = x0 + j;
                         // a 4-pixel group never straddles a tile (bits >= 2); tiles beyond the row's end are never read
-                        if ((j & 3) == 0) tile_mode = tile_row[4 * (min(x, w - 1) >> bits) + 1] & 15;
+                        if ((j & 3) == 0) tile_mode = mode_of[j >> 2];
                         uint32_t pred;
                         if (y == 0) pred = x == 0 ? 0xff000000u : Lpx;            // first row: black / L (:40-53)
                         else if (x == 0) pred = T4[0];                            // first column: T (:61-64)
@@ -337,6 +373,67 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                         if (x < w) Lpx = res[j];
                         if (x == 0) first_px = res[j];
                     }
+#else
+                    // The lanes of a wavefront hold different modes, and a 14-way switch per pixel costs more in exec-mask
+                    // bookkeeping (47 SALU per pixel) than in arithmetic.  So: per 4-pixel group (one tile, one mode per lane)
+                    // the mode becomes a handful of lane masks; everything that does not involve L is computed for the group
+                    // up front; the modes that average L with its neighbours (1, 5, 6, 7, 10) share one chain
+                    // avg(avg(L, A), B) with per-lane A, B; and only select / clamp-add-subtract (11-13) keep a branch, taken
+                    // when some lane of the wavefront has that mode.
+                    // the row's first output does not depend on L (black or T is added): known before the groups below
+                    // fold it into the TR of the row's last pixel, which can sit in the same group (w <= 4)
+                    if (x0 == 0) first_px = add_px(in[0], y == 0 ? 0xff000000u : T4[0]);
+#pragma unroll
+                    for (int g4 = 0; g4 < kPC / 4; ++g4) {
+                        const int xg = x0 + 4 * g4;
+                        const int m = mode_of[g4];
+                        const bool m5 = m == 5, m10 = m == 10, is_l = m == 1;
+                        const bool use_b = m5 || m10;
+                        const bool chain = is_l || use_b || m == 6 || m == 7;
+                        const bool any11 = __builtin_amdgcn_ballot_w64(m == 11) != 0, any12 = __builtin_amdgcn_ballot_w64(m == 12) != 0,
+                                   any13 = __builtin_amdgcn_ballot_w64(m == 13) != 0;
+                        uint32_t A[4], B[4], N[4], TLv[4];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int j = 4 * g4 + jj, x = xg + jj;
+                            const uint32_t T = T4[j];
+                            const uint32_t TL = j ? T4[j - 1] : TLfirst;
+                            uint32_t TR = j < kPC - 1 ? T4[j + 1] : Tn[0];
+                            if (x == w - 1) TR = first_px;                        // linear addressing: top+4 is the row's own first pixel (known: x > 0 here)
+                            const uint32_t aTTR = avg_px(T, TR);
+                            TLv[jj] = TL;
+                            A[jj] = m5 ? TR : (m == 7 ? T : TL);
+                            B[jj] = m5 ? T : aTTR;
+                            uint32_t n = 0u;                                      // modes 14, 15: nothing is added
+                            n = m == 0 ? 0xff000000u : n;
+                            n = m == 2 ? T : n;
+                            n = m == 3 ? TR : n;
+                            n = m == 4 ? TL : n;
+                            n = m == 8 ? avg_px(TL, T) : n;
+                            n = m == 9 ? aTTR : n;
+                            N[jj] = n;
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int j = 4 * g4 + jj, x = xg + jj;
+                            const uint32_t L = Lpx, T = T4[j];
+                            const uint32_t X = avg_px(L, A[jj]);
+                            uint32_t pr = use_b ? avg_px(X, B[jj]) : X;
+                            pr = is_l ? L : pr;
+                            pr = chain ? pr : N[jj];
+                            if (any11) {     // select: l = sum|TL - T|, t = sum|TL - L|; L if l < t else T
+                                const uint32_t l = __builtin_amdgcn_sad_u8(TLv[jj], T, 0u), t = __builtin_amdgcn_sad_u8(TLv[jj], L, 0u);
+                                pr = m == 11 ? (l < t ? L : T) : pr;
+                            }
+                            if (any12) pr = m == 12 ? predict_px(12, L, T, TLv[jj], 0u) : pr;
+                            if (any13) pr = m == 13 ? predict_px(13, L, T, TLv[jj], 0u) : pr;
+                            uint32_t pred = x == 0 ? T4[0] : pr;                  // first column: T (:61-64)
+                            pred = y == 0 ? (x == 0 ? 0xff000000u : L) : pred;    // first row: black / L (:40-53)
+                            res[j] = add_px(in[j], pred);
+                            Lpx = x < w ? res[j] : Lpx;
+                        }
+                    }
+#endif
                     if (keep_raw) {
                         if (x0 + kPC <= w) {
 #pragma unroll
@@ -376,11 +473,16 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                     for (int j = 0; j < kPC; ++j) P1[j] = res[j];
                 }
                 if (has_below) {
+                    // What is announced is the count reached two steps ago: its stores have had two steps to land, so the
+                    // release fence (s_waitcnt vmcnt(0)) does not stall the band on the stores it has only just issued.
                     const int k_last = c - 2 * (kPredRows - 1);
-                    if (k_last >= 0 && (((k_last + 1) * kPC) % 16 == 0 || k_last == n_chunks - 1))
-                        publish_progress(&progress[wave], (q << kPredSeqShift) | uint32_t(min(kPC * (k_last + 1), w)));
+                    if (k_last >= 0 && (((k_last + 1) * kPC) % 16 == 0 || k_last == n_chunks - 1)) {
+                        if (pending_publish) publish_progress(&progress[wave], pending_publish);
+                        pending_publish = (q << kPredSeqShift) | uint32_t(min(kPC * (k_last + 1), w));
+                    }
                 }
             }
+            if (has_below && pending_publish) publish_progress(&progress[wave], pending_publish);      // the band's last rows are out
         }
         seq += uint32_t(n_bands);
     }
@@ -515,7 +617,7 @@ extern "C" int wpk_launch_vp8l(int n, const wp_vp8l_frame* fh, const wp_vp8l_fra
                 if (idx >= 0) have[fh[i].t[idx].type] = true;
             }
             if (have[0])
-                hipLaunchKernelGGL(vp8l_predictor_kernel, dim3(std::min(cnt, 1024)), dim3(kWavesPerWG * kWave), 0, stream,
+                hipLaunchKernelGGL(vp8l_predictor_kernel, dim3(std::min(cnt, 1024)), dim3(kPredWaves * kWave), 0, stream,
                                    cnt, fdc, pass, d_pix, d_tmp, d_aux, d_out, swizzle);
             if (have[1]) hipLaunchKernelGGL(vp8l_cross_color_kernel, dim3(gx, cnt), dim3(256), 0, stream, fdc, pass, d_pix, d_tmp, d_aux);
             if (have[2]) hipLaunchKernelGGL(vp8l_subtract_green_kernel, dim3(gx, cnt), dim3(256), 0, stream, fdc, pass, d_pix, d_tmp, swizzle);
