@@ -12,7 +12,7 @@
 // for every frame, its transform number n_transforms-1-p.  The per-pixel transforms are pure
 // streaming kernels (one dword per lane, coalesced).  The predictor is a row wavefront: pixel (x,y)
 // needs L, TL, T, TR, so row y may trail row y-1 by a few pixels; one wavefront owns 64 rows
-// (lane = row), rows are skewed by two 4-pixel chunks and exchange their finished chunks with DPP-free
+// (lane = row), rows are skewed by one 8-pixel chunk and exchange their finished chunks with DPP-free
 // lane shuffles; 64-row bands are pipelined across the wavefronts of a workgroup through an LDS
 // progress word, the boundary row going through memory (workgroup-scope release/acquire).
 #include "wp_device.h"
@@ -204,17 +204,18 @@ __device__ __forceinline__ uint32_t predict_px(int mode, uint32_t L, uint32_t T,
 struct __attribute__((aligned(4))) Px4 { uint32_t v[4]; };
 constexpr uint32_t kPredSeqShift = 15;      // progress word = (band sequence << 15) | pixels finished in the band's last row
 constexpr int kPredRows = 64;
-// Wavefronts per workgroup (= bands of one frame that can be in flight).  A band trails the one above by 126 steps and
-// lasts n_chunks + 126, so only about three are ever active; registers held by idle wavefronts cost resident frames.
+// Wavefronts per workgroup (= bands of one frame that can be in flight).  A band trails the one above by 64 steps and
+// lasts n_chunks + 63, so four or five are active at a time.  Four is best (1024 x 1080p: 10.0 ms; 5, 6, 8: 12.5 ms; a
+// single frame 3.6 vs 4.0 ms): each wavefront of the workgroup then has a SIMD to itself, and the pass is bound by the
+// latency of the per-step dependency chain; registers held by waiting wavefronts also cost resident frames.
 #ifndef WP_PRED_WAVES
 #define WP_PRED_WAVES 4
 #endif
 constexpr int kPredWaves = WP_PRED_WAVES;
-// Pixels a lane handles per step.  Every lane walks its own row, so a step touches 64 different rows: with 4 pixels
-// (16 bytes) per row the kernel is bound by the L2 request rate (tools/ubench/row_access.hip: row-strided 16-byte
-// accesses reach 1.1 / 1.7 TB/s for loads / stores, 32-byte ones 3.3 / 1.9 TB/s); with more pixels per step the
-// two-chunk skew between rows costs more idle steps per band.  Measured on 1024 x 1080p, whole chain: 4 px 19.4 ms,
-// 8 px 15.9 ms, 16 px 30.6 ms, 32 px 57.5 ms.
+// Pixels a lane handles per step (two 4-pixel groups: the TR hand-over of the one-chunk skew sits between them).  Every
+// lane walks its own row, so a step touches 64 different rows (tools/ubench/row_access.hip: row-strided 16-byte
+// accesses reach 1.1 / 1.7 TB/s for loads / stores, 32-byte ones 3.3 / 1.9 TB/s).  Measured with the earlier two-chunk
+// skew on 1024 x 1080p, whole chain: 4 px 19.4 ms, 8 px 15.9 ms, 16 px 30.6 ms, 32 px 57.5 ms.
 #ifndef WP_PRED_CHUNK
 #define WP_PRED_CHUNK 8
 #endif
@@ -260,7 +261,12 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
             const bool has_above = band > 0, has_below = band + 1 < n_bands;
             const int prev_wave = (wave + kPredWaves - 1) % kPredWaves;
             const int rows_here = min(kPredRows, h - band * kPredRows);
-            const int n_steps = n_chunks + 2 * (rows_here - 1);
+            // Row r trails row r-1 by ONE chunk: of the row above, chunk k (T, TL, and TR of all pixels but the chunk's last)
+            // is what lane r-1 produced in the previous step; the TR of the last pixel is the first pixel lane r-1
+            // produces in this very step -- every lane runs the same instruction, so it is shuffled down between the
+            // chunk's two 4-pixel groups.  The pass is bound by a frame's latency (three frames take as long as three
+            // hundred): (bands - 1) x 64 rows x skew + chunks per row steps, so the skew is what counts.
+            const int n_steps = n_chunks + (rows_here - 1);
             uint32_t* row = base + (long long)(row_ok ? y : 0) * w;
             const uint32_t* above_row = base + (long long)(y > 0 ? y - 1 : 0) * w;
             const uint8_t* tile_row = tiles + 4 * ((row_ok ? y : 0) >> bits) * tpr;
@@ -269,15 +275,18 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
             // the next band reads this band's last row back (unrotated, before subtract-green): that row is also stored in place
             const bool keep_raw = !to_out || (has_below && r == kPredRows - 1);
 
-            uint32_t P1[kPC], T4[kPC], Tn[kPC];     // my previous chunk's outputs (what the row below fetches); row above: this chunk, next chunk
+            uint32_t P1[kPC], T4[kPC];              // my previous chunk's outputs (what the row below fetches); row above, this chunk
+            uint32_t An[kPC + 1];                   // band's first row: chunk c+1 of the row above and the pixel after it, read a step ahead
 #pragma unroll
-            for (int j = 0; j < kPC; ++j) { P1[j] = 0; T4[j] = 0; Tn[j] = 0; }
+            for (int j = 0; j < kPC; ++j) { P1[j] = 0; T4[j] = 0; }
+#pragma unroll
+            for (int j = 0; j <= kPC; ++j) An[j] = 0;
             uint32_t TLfirst = 0, Lpx = 0, first_px = 0;
             uint32_t avail = 0;                     // pixels of the row above known to be finished (band boundary)
             uint32_t pending_publish = 0;
             // A step's own inputs (its 8 pixels, the tile modes of its two 4-pixel groups, the cross-colour multipliers)
-            // depend on nothing the wavefront computes, so they are fetched one step ahead: with two or three bands of a
-            // frame in flight there are too few wavefronts per SIMD to hide a load issued where it is used.
+            // depend on nothing the wavefront computes, so they are fetched one step ahead: with a few bands of a frame in
+            // flight there are too few wavefronts per SIMD to hide a load issued where it is used.
             uint32_t nx_in[kPC], nx_mode[kPC / 4], nx_cc[kPC / 4];
 #pragma unroll
             for (int j = 0; j < kPC; ++j) nx_in[j] = 0;
@@ -304,32 +313,45 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                     if (cc) nx_cc[g4] = cc_row[min(xx + 4 * g4, w - 1) >> cc_bits];
                 }
             };
-            fetch(-2 * r);
+            fetch(-r);
+            auto wait_above = [&](uint32_t need) {
+                if (avail < need) {
+                    const uint32_t target = ((q - 1) << kPredSeqShift) | need;
+                    uint32_t v;
+                    while ((v = __hip_atomic_load(&progress[prev_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+                        __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    avail = (v >> kPredSeqShift) == (q - 1) ? (v & ((1u << kPredSeqShift) - 1u)) : uint32_t(w);
+                }
+            };
+            if (has_above) {
+                wait_above(uint32_t(min(kPC + 1, w)));
+                if (r == 0) {
+#pragma unroll
+                    for (int j = 0; j <= kPC; ++j) An[j] = (j < w) ? above_row[j] : 0u;
+                }
+            }
 
             for (int c = 0; c < n_steps; ++c) {
-                const int k = c - 2 * r;
+                const int k = c - r;
                 const bool act = row_ok && k >= 0 && k < n_chunks;
-                // ---- fetch chunk k+1 of the row above: from lane r-1 (its previous chunk), or from memory for the band's first row
+                // ---- chunk k of the row above: lane r-1's previous outputs, or memory for the band's first row
 #pragma unroll
-                for (int j = 0; j < kPC; ++j) { T4[j] = Tn[j]; Tn[j] = __shfl_up(P1[j], 1); }
-                if (has_above && c + 1 < n_chunks + 1) {
-                    // lane 0 is about to need pixels up to kPC*(c+2)-1 of row y-1
-                    const uint32_t need = uint32_t(min(kPC * (c + 2), w));
-                    if (avail < need) {
-                        const uint32_t target = ((q - 1) << kPredSeqShift) | need;
-                        uint32_t v;
-                        while ((v = __hip_atomic_load(&progress[prev_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
-                            __builtin_amdgcn_s_sleep(1);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        avail = (v >> kPredSeqShift) == (q - 1) ? (v & ((1u << kPredSeqShift) - 1u)) : uint32_t(w);
-                    }
+                for (int j = 0; j < kPC; ++j) T4[j] = __shfl_up(P1[j], 1);
+                uint32_t tr_mem = 0;
+                if (has_above) {
                     if (r == 0) {
-                        const int x0 = kPC * (c + 1);
 #pragma unroll
-                        for (int j = 0; j < kPC; ++j) Tn[j] = (x0 + j < w) ? above_row[x0 + j] : 0u;
-                        if (c == 0) {
+                        for (int j = 0; j < kPC; ++j) T4[j] = An[j];
+                        tr_mem = An[kPC];
+                    }
+                    if (c + 1 < n_chunks) {
+                        // lane 0 is about to read pixels up to kPC*(c+2) of row y-1
+                        wait_above(uint32_t(min(kPC * (c + 2) + 1, w)));
+                        if (r == 0) {
+                            const int x1 = kPC * (c + 1);
 #pragma unroll
-                            for (int j = 0; j < kPC; ++j) T4[j] = (j < w) ? above_row[j] : 0u;
+                            for (int j = 0; j <= kPC; ++j) An[j] = (x1 + j < w) ? above_row[x1 + j] : 0u;
                         }
                     }
                 }
@@ -342,98 +364,82 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
 #pragma unroll
                 for (int g4 = 0; g4 < kPC / 4; ++g4) { mode_of[g4] = int(nx_mode[g4] & 15); cc_of[g4] = nx_cc[g4]; }
                 fetch(k + 1);
-                if (act) {
-                    const int x0 = kPC * k;
-                    uint32_t res[kPC];
+                const int x0 = kPC * k;
+                uint32_t res[kPC];
+#pragma unroll
+                for (int j = 0; j < kPC; ++j) res[j] = 0;
+                // the row's first output does not depend on L (black or T is added): known before the groups below fold it
+                // into the TR of the row's last pixel, which can sit in the same group (w <= 4)
+                if (act && x0 == 0) first_px = add_px(cc ? cross_color_px(in[0], cc_of[0]) : in[0], y == 0 ? 0xff000000u : T4[0]);
+                uint32_t tr_last = 0;
+                static_assert(kPC == 8, "two 4-pixel groups per chunk");
+                // The lanes of a wavefront hold different modes, and a 14-way switch per pixel costs more in exec-mask
+                // bookkeeping (47 SALU per pixel) than in arithmetic.  So: per 4-pixel group (one tile, one mode per lane) the
+                // mode becomes a handful of lane masks; everything that does not involve L is computed for the group up
+                // front; the modes that average L with its neighbours (1, 5, 6, 7, 10) share one chain avg(avg(L, A), B)
+                // with per-lane A, B; and only select / clamp-add-subtract (11-13) keep a branch, taken when some lane of
+                // the wavefront has that mode.
+#pragma unroll
+                for (int g4 = 0; g4 < kPC / 4; ++g4) {
+                    if (g4 == 1) {
+                        // the row above has just produced the pixel that is TR of this chunk's last pixel (every lane takes part)
+                        const uint32_t tr_shfl = __shfl_up(res[0], 1);
+                        tr_last = (has_above && r == 0) ? tr_mem : tr_shfl;
+                    }
+                    if (!act) continue;
                     if (cc) {                // inverseCrossColor of the pixels loaded (a 4-pixel group never straddles a tile: bits >= 2)
 #pragma unroll
-                        for (int g4 = 0; g4 < kPC / 4; ++g4) {
-                            const uint32_t t = cc_of[g4];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) in[4 * g4 + j] = cross_color_px(in[4 * g4 + j], t);
-                        }
+                        for (int jj = 0; jj < 4; ++jj) in[4 * g4 + jj] = cross_color_px(in[4 * g4 + jj], cc_of[g4]);
                     }
-#ifdef WP_PRED_BRANCHY
-                    int tile_mode = 0;
+                    const int xg = x0 + 4 * g4;
+                    const int m = mode_of[g4];
+                    const bool m5 = m == 5, m10 = m == 10, is_l = m == 1;
+                    const bool use_b = m5 || m10;
+                    const bool chain = is_l || use_b || m == 6 || m == 7;
+                    const bool any11 = __builtin_amdgcn_ballot_w64(m == 11) != 0, any12 = __builtin_amdgcn_ballot_w64(m == 12) != 0,
+                               any13 = __builtin_amdgcn_ballot_w64(m == 13) != 0;
+                    uint32_t A[4], B[4], N[4], TLv[4];
 #pragma unroll
-                    for (int j = 0; j < kPC; ++j) {
-                        const int x = x0 + j;
-                        // a 4-pixel group never straddles a tile (bits >= 2); tiles beyond the row's end are never read
-                        if ((j & 3) == 0) tile_mode = mode_of[j >> 2];
-                        uint32_t pred;
-                        if (y == 0) pred = x == 0 ? 0xff000000u : Lpx;            // first row: black / L (:40-53)
-                        else if (x == 0) pred = T4[0];                            // first column: T (:61-64)
-                        else {
-                            const uint32_t TL = j ? T4[j - 1] : TLfirst;
-                            uint32_t TR = j < kPC - 1 ? T4[j + 1] : Tn[0];
-                            if (x == w - 1) TR = first_px;                        // linear addressing: top+4 is the row's own first pixel
-                            pred = predict_px(tile_mode, Lpx, T4[j], TL, TR);
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int j = 4 * g4 + jj, x = xg + jj;
+                        const uint32_t T = T4[j];
+                        const uint32_t TL = j ? T4[j - 1] : TLfirst;
+                        uint32_t TR = j < kPC - 1 ? T4[j + 1] : tr_last;
+                        if (x == w - 1) TR = first_px;                        // linear addressing: top+4 is the row's own first pixel
+                        const uint32_t aTTR = avg_px(T, TR);
+                        TLv[jj] = TL;
+                        A[jj] = m5 ? TR : (m == 7 ? T : TL);
+                        B[jj] = m5 ? T : aTTR;
+                        uint32_t n = 0u;                                      // modes 14, 15: nothing is added
+                        n = m == 0 ? 0xff000000u : n;
+                        n = m == 2 ? T : n;
+                        n = m == 3 ? TR : n;
+                        n = m == 4 ? TL : n;
+                        n = m == 8 ? avg_px(TL, T) : n;
+                        n = m == 9 ? aTTR : n;
+                        N[jj] = n;
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int j = 4 * g4 + jj, x = xg + jj;
+                        const uint32_t L = Lpx, T = T4[j];
+                        const uint32_t X = avg_px(L, A[jj]);
+                        uint32_t pr = use_b ? avg_px(X, B[jj]) : X;
+                        pr = is_l ? L : pr;
+                        pr = chain ? pr : N[jj];
+                        if (any11) {     // select: l = sum|TL - T|, t = sum|TL - L|; L if l < t else T
+                            const uint32_t l = __builtin_amdgcn_sad_u8(TLv[jj], T, 0u), t = __builtin_amdgcn_sad_u8(TLv[jj], L, 0u);
+                            pr = m == 11 ? (l < t ? L : T) : pr;
                         }
+                        if (any12) pr = m == 12 ? predict_px(12, L, T, TLv[jj], 0u) : pr;
+                        if (any13) pr = m == 13 ? predict_px(13, L, T, TLv[jj], 0u) : pr;
+                        uint32_t pred = x == 0 ? T4[0] : pr;                  // first column: T (:61-64)
+                        pred = y == 0 ? (x == 0 ? 0xff000000u : L) : pred;    // first row: black / L (:40-53)
                         res[j] = add_px(in[j], pred);
-                        if (x < w) Lpx = res[j];
-                        if (x == 0) first_px = res[j];
+                        Lpx = x < w ? res[j] : Lpx;
                     }
-#else
-                    // The lanes of a wavefront hold different modes, and a 14-way switch per pixel costs more in exec-mask
-                    // bookkeeping (47 SALU per pixel) than in arithmetic.  So: per 4-pixel group (one tile, one mode per lane)
-                    // the mode becomes a handful of lane masks; everything that does not involve L is computed for the group
-                    // up front; the modes that average L with its neighbours (1, 5, 6, 7, 10) share one chain
-                    // avg(avg(L, A), B) with per-lane A, B; and only select / clamp-add-subtract (11-13) keep a branch, taken
-                    // when some lane of the wavefront has that mode.
-                    // the row's first output does not depend on L (black or T is added): known before the groups below
-                    // fold it into the TR of the row's last pixel, which can sit in the same group (w <= 4)
-                    if (x0 == 0) first_px = add_px(in[0], y == 0 ? 0xff000000u : T4[0]);
-#pragma unroll
-                    for (int g4 = 0; g4 < kPC / 4; ++g4) {
-                        const int xg = x0 + 4 * g4;
-                        const int m = mode_of[g4];
-                        const bool m5 = m == 5, m10 = m == 10, is_l = m == 1;
-                        const bool use_b = m5 || m10;
-                        const bool chain = is_l || use_b || m == 6 || m == 7;
-                        const bool any11 = __builtin_amdgcn_ballot_w64(m == 11) != 0, any12 = __builtin_amdgcn_ballot_w64(m == 12) != 0,
-                                   any13 = __builtin_amdgcn_ballot_w64(m == 13) != 0;
-                        uint32_t A[4], B[4], N[4], TLv[4];
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            const int j = 4 * g4 + jj, x = xg + jj;
-                            const uint32_t T = T4[j];
-                            const uint32_t TL = j ? T4[j - 1] : TLfirst;
-                            uint32_t TR = j < kPC - 1 ? T4[j + 1] : Tn[0];
-                            if (x == w - 1) TR = first_px;                        // linear addressing: top+4 is the row's own first pixel (known: x > 0 here)
-                            const uint32_t aTTR = avg_px(T, TR);
-                            TLv[jj] = TL;
-                            A[jj] = m5 ? TR : (m == 7 ? T : TL);
-                            B[jj] = m5 ? T : aTTR;
-                            uint32_t n = 0u;                                      // modes 14, 15: nothing is added
-                            n = m == 0 ? 0xff000000u : n;
-                            n = m == 2 ? T : n;
-                            n = m == 3 ? TR : n;
-                            n = m == 4 ? TL : n;
-                            n = m == 8 ? avg_px(TL, T) : n;
-                            n = m == 9 ? aTTR : n;
-                            N[jj] = n;
-                        }
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            const int j = 4 * g4 + jj, x = xg + jj;
-                            const uint32_t L = Lpx, T = T4[j];
-                            const uint32_t X = avg_px(L, A[jj]);
-                            uint32_t pr = use_b ? avg_px(X, B[jj]) : X;
-                            pr = is_l ? L : pr;
-                            pr = chain ? pr : N[jj];
-                            if (any11) {     // select: l = sum|TL - T|, t = sum|TL - L|; L if l < t else T
-                                const uint32_t l = __builtin_amdgcn_sad_u8(TLv[jj], T, 0u), t = __builtin_amdgcn_sad_u8(TLv[jj], L, 0u);
-                                pr = m == 11 ? (l < t ? L : T) : pr;
-                            }
-                            if (any12) pr = m == 12 ? predict_px(12, L, T, TLv[jj], 0u) : pr;
-                            if (any13) pr = m == 13 ? predict_px(13, L, T, TLv[jj], 0u) : pr;
-                            uint32_t pred = x == 0 ? T4[0] : pr;                  // first column: T (:61-64)
-                            pred = y == 0 ? (x == 0 ? 0xff000000u : L) : pred;    // first row: black / L (:40-53)
-                            res[j] = add_px(in[j], pred);
-                            Lpx = x < w ? res[j] : Lpx;
-                        }
-                    }
-#endif
+                }
+                if (act) {
                     if (keep_raw) {
                         if (x0 + kPC <= w) {
 #pragma unroll
@@ -475,7 +481,7 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                 if (has_below) {
                     // What is announced is the count reached two steps ago: its stores have had two steps to land, so the
                     // release fence (s_waitcnt vmcnt(0)) does not stall the band on the stores it has only just issued.
-                    const int k_last = c - 2 * (kPredRows - 1);
+                    const int k_last = c - (kPredRows - 1);
                     if (k_last >= 0 && (((k_last + 1) * kPC) % 16 == 0 || k_last == n_chunks - 1)) {
                         if (pending_publish) publish_progress(&progress[wave], pending_publish);
                         pending_publish = (q << kPredSeqShift) | uint32_t(min(kPC * (k_last + 1), w));
