@@ -285,7 +285,9 @@ int wp_vp8l_inverse_dev(int n, const wp_vp8l_frame* fh, const wp_vp8l_frame* fd,
     if (swizzle < WP_SWIZZLE_NONE || swizzle > WP_SWIZZLE_GREEN) return fail(WP_ERR_INVALID, "bad swizzle");
     for (int i = 0; i < n; ++i) {
         const wp_vp8l_frame& a = fh[i];
-        if (a.width <= 0 || a.height <= 0 || a.coded_width <= 0 || a.n_transforms < 0 || a.n_transforms > WP_VP8L_MAX_TRANSFORMS ||
+        // 14-bit dimensions + 1 (Vp8LDecoder.hx header): the kernels count pixels in 31 bits and a row's progress in 15
+        if (a.width <= 0 || a.height <= 0 || a.width > 16384 || a.height > 16384 || a.coded_width <= 0 || a.coded_width > 16384 ||
+            a.n_transforms < 0 || a.n_transforms > WP_VP8L_MAX_TRANSFORMS ||
             (a.pix_off & 15) || (a.out_off & 15) || (a.tmp_off & 15))
             return fail(WP_ERR_INVALID, "bad wp_vp8l_frame at index " + std::to_string(i));
         // The kernels derive every buffer extent from the transform list: check that the list is consistent with the frame

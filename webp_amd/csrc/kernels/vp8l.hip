@@ -97,10 +97,15 @@ void vp8l_cross_color_kernel(const wp_vp8l_frame* __restrict__ frames, int pass,
     const int w = fr.t[idx].old_width, bits = fr.t[idx].bits;
     const int tpr = n_tiles(w, bits);
     const uint32_t* tiles = reinterpret_cast<const uint32_t*>(aux + fr.t[idx].data_off);
-    const long long total = (long long)w * fr.height;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int y = int(i / w), x = int(i - (long long)y * w);
+    // w, height <= 16384: pixel indices fit in 31 bits; (x, y) advance incrementally (one division per lane, not per pixel)
+    const int total = w * fr.height, stride = int(gridDim.x * blockDim.x);
+    const int qs = stride / w, rs = stride - qs * w;
+    int i = int(blockIdx.x * blockDim.x + threadIdx.x);
+    int y = i / w, x = i - y * w;
+    for (; i < total; i += stride) {
         p[i] = cross_color_px(p[i], tiles[(y >> bits) * tpr + (x >> bits)]);
+        x += rs; y += qs;
+        if (x >= w) { x -= w; ++y; }
     }
 }
 
@@ -128,11 +133,17 @@ void vp8l_color_indexing_kernel(const wp_vp8l_frame* __restrict__ frames, int pa
     const int pw = loc.width;                                                // packed row length = nTiles(oldWidth, bits)
     const int bpp = 8 >> bits, xmask = (1 << bits) - 1;
     const uint32_t vmask = (1u << bpp) - 1u;
-    const long long total = (long long)w * fr.height;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int y = int(i / w), x = int(i - (long long)y * w);
-        const uint32_t g = (src[(long long)y * pw + (x >> bits)] >> 8) & 0xff;
+    // w, height <= 16384: pixel indices fit in 31 bits; (x, y) advance incrementally (one division per lane, not per pixel)
+    const int total = w * fr.height, stride = int(gridDim.x * blockDim.x);
+    const int qs = stride / w, rs = stride - qs * w;
+    int i = int(blockIdx.x * blockDim.x + threadIdx.x);
+    int y = i / w, x = i - y * w;
+#pragma unroll 4
+    for (; i < total; i += stride) {
+        const uint32_t g = (src[y * pw + (x >> bits)] >> 8) & 0xff;
         dst[i] = swizzled(palette[(g >> ((x & xmask) * bpp)) & vmask], sw);
+        x += rs; y += qs;
+        if (x >= w) { x -= w; ++y; }
     }
 }
 
@@ -602,7 +613,7 @@ void alpha_unfilter_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* a
 namespace {
 int grid_for(long long items, int n_frames) {
     long long g = (items + 255) / 256;
-    const long long cap = std::max(8LL, 16384LL / std::max(1, n_frames));
+    const long long cap = std::max(8LL, 65536LL / std::max(1, n_frames));     // frames a kernel has nothing to do for leave at once: plenty of blocks
     return int(std::max(1LL, std::min(g, cap)));
 }
 }  // namespace
