@@ -242,3 +242,11 @@ def test_inconsistent_transform_lists_are_refused():
                            pix=np.zeros(4 * ((w + 1) // 2) * h, np.uint8)), "transform data too short")):
         with pytest.raises(WebPError, match=msg):
             _run_chain([bad])
+    # dimensions beyond what a VP8L header can hold (14 bits + 1) are refused before anything is sized from them
+    from webp_amd._lib import Vp8lFrame, lib, check
+    desc = (Vp8lFrame * 1)()
+    desc[0].width, desc[0].height, desc[0].coded_width = 16385, 1, 16385
+    buf = np.zeros(4 * 16385 + 64, np.uint8)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    with pytest.raises(WebPError, match="bad wp_vp8l_frame"):
+        check(lib().wp_vp8l_inverse(1, desc, vp(buf), buf.size, vp(buf), 16, vp(buf.copy()), buf.size, 0))
