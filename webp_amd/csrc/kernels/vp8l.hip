@@ -213,6 +213,11 @@ __device__ __forceinline__ uint32_t predict_px(int mode, uint32_t L, uint32_t T,
 }
 
 struct __attribute__((aligned(4))) Px4 { uint32_t v[4]; };
+// value of the lane above (lane r-1) as one DPP move (wave_shr:1; gfx9 has it) instead of a trip through the LDS
+// crossbar (ds_bpermute): these hand-overs sit on the per-step dependency chain.  Lane 0 gets 0 and never uses it.
+__device__ __forceinline__ uint32_t from_lane_above(uint32_t v) {
+    return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x138, 0xf, 0xf, true));
+}
 constexpr uint32_t kPredSeqShift = 15;      // progress word = (band sequence << 15) | pixels finished in the band's last row
 constexpr int kPredRows = 64;
 // Wavefronts per workgroup (= bands of one frame that can be in flight).  A band trails the one above by 64 steps and
@@ -348,7 +353,7 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                 const bool act = row_ok && k >= 0 && k < n_chunks;
                 // ---- chunk k of the row above: lane r-1's previous outputs, or memory for the band's first row
 #pragma unroll
-                for (int j = 0; j < kPC; ++j) T4[j] = __shfl_up(P1[j], 1);
+                for (int j = 0; j < kPC; ++j) T4[j] = from_lane_above(P1[j]);
                 uint32_t tr_mem = 0;
                 if (has_above) {
                     if (r == 0) {
@@ -394,7 +399,7 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                 for (int g4 = 0; g4 < kPC / 4; ++g4) {
                     if (g4 == 1) {
                         // the row above has just produced the pixel that is TR of this chunk's last pixel (every lane takes part)
-                        const uint32_t tr_shfl = __shfl_up(res[0], 1);
+                        const uint32_t tr_shfl = from_lane_above(res[0]);
                         tr_last = (has_above && r == 0) ? tr_mem : tr_shfl;
                     }
                     if (!act) continue;
