@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="one stream per step, no overlap between steps (kernel times as when each runs alone)")
     ap.add_argument("--split", type=float, default=0.6, help="share of a step's frames whose finishing pass runs beside the next reconstruction (the rest: beside the next loop filter)")
     ap.add_argument("--finish-delay-us", type=float, default=40.0, help="how long a finishing pass is held back so that the persistent kernel of its phase is dispatched first")
+    ap.add_argument("--one-launch", action="store_true", help="reconstruction + loop filter as one launch, the whole finishing pass of the step before beside it")
     ap.add_argument("--alone", action="store_true", help="after the timed region also time the single-stream fused call (config.serial_ms_per_step)")
     args = ap.parse_args()
 
@@ -122,7 +123,7 @@ def main():
         torch.cuda.synchronize()
 
     from webp_amd.device import LossyPipeline
-    pipe = None if args.serial else LossyPipeline(device, split=args.split, finish_delay_us=args.finish_delay_us)
+    pipe = None if args.serial else LossyPipeline(device, split=args.split, finish_delay_us=args.finish_delay_us, one_launch=args.one_launch)
     if pipe is not None:
         db.second_workspace()                        # allocated here, not by the first odd step inside the timed region
 
@@ -193,6 +194,9 @@ def main():
            "vp8_filter_kernel": batch.filt.nbytes + 2 * yuv_bytes,
            "vp8_finish_kernel": 2 * yuv_bytes + argb_bytes}       # tiles in, row-major planes + ARGB out
     times = {"vp8_recon_kernel": t_recon, "vp8_filter_kernel": t_filter, "vp8_finish_kernel": t_conv}
+    if pipe is not None and args.one_launch:         # reconstruction + loop filter are one kernel: packed inputs in, S tiles out
+        alg = {"vp8_recon_filter_kernel": in_bytes + yuv_bytes, "vp8_finish_kernel": alg["vp8_finish_kernel"]}
+        times = {"vp8_recon_filter_kernel": t_recon, "vp8_finish_kernel": t_conv}
     dom = max(times, key=times.get)
     achieved = alg[dom] / (times[dom] * 1e-3) / 1e9                    # bytes per step / time per step = bytes per launch / time per launch
     launches = finish_per_step if dom == "vp8_finish_kernel" else 1.0

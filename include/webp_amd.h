@@ -145,6 +145,14 @@ int wp_vp8_loopfilter_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_f
                           const uint32_t* d_filt, void* d_work, size_t work_bytes,
                           uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, void* stream);
 
+/* wp_vp8_recon_dev followed by wp_vp8_loopfilter_dev (workspace variants) as ONE launch: each persistent
+ * workgroup reconstructs its frames and then filters the same frames, so workgroups whose frames were
+ * cheap to reconstruct are already filtering while others still reconstruct.  Same results, same
+ * workspace contents afterwards (R tiles, and S tiles of the frames with a loop filter). */
+int wp_vp8_recon_filter_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
+                            const uint32_t* d_mb, const uint32_t* d_filt, const int16_t* d_coeff,
+                            void* d_work, size_t work_bytes, void* stream);
+
 /* Finishing pass: workspace tiles -> row-major MB-padded planes (ImageData.Yuv420, Vp8Decoder.ensureImg
  * geometry; optional) and tightly packed A,R,G,B (Tools.toArgb, Tools.hx:6-48; optional).  Frames with
  * filter_type == 0 are taken from the R tiles, all others from the S tiles. */

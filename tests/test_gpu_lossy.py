@@ -116,6 +116,36 @@ def test_staged_workspace_path_equals_fused(dev_batch):
         assert torch.equal(db.argb[d.argb_off:d.argb_off + 4 * d.width * d.height], ref[d.argb_off:d.argb_off + 4 * d.width * d.height]), n
 
 
+def test_one_launch_recon_filter_equals_two_launches(dev_batch):
+    """wp_vp8_recon_filter_dev (each workgroup reconstructs its frames, then filters them) leaves the workspace as
+    wp_vp8_recon_dev + wp_vp8_loopfilter_dev do: same planes and ARGB from the finishing pass, also through
+    LossyPipeline(one_launch=True)."""
+    import torch
+    from webp_amd.device import LossyPipeline
+    names, files, ora, db = dev_batch
+    db.recon(planes=False); db.loopfilter(planes=False); db.finish()
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in (db.argb, db.y, db.u, db.v)]
+    for variant in ("direct", "pipeline"):
+        for t in (db.argb, db.y, db.u, db.v):
+            t.zero_()
+        db.work.zero_()
+        if variant == "direct":
+            db.recon_filter(); db.finish()
+        else:
+            pipe = LossyPipeline(one_launch=True)
+            for _ in range(3):
+                pipe.submit(db)
+            pipe.drain()
+        torch.cuda.synchronize()
+        for i in range(db.b.n):
+            d = db.b.desc[i]
+            nmb = d.mbw * d.mbh
+            for got, exp, off, sz, what in ((db.argb, ref[0], d.argb_off, 4 * d.width * d.height, "argb"), (db.y, ref[1], d.y_off, 256 * nmb, "y"),
+                                            (db.u, ref[2], d.u_off, 64 * nmb, "u"), (db.v, ref[3], d.v_off, 64 * nmb, "v")):
+                assert torch.equal(got[off:off + sz], exp[off:off + sz]), (variant, names[i] if i < len(names) else i, what)
+
+
 @pytest.mark.parametrize("split", [0.5, 0.0, 0.3, 1.0])
 def test_pipelined_steps_equal_serial(dev_batch, split):
     """LossyPipeline (the finishing pass of one step, in two frame ranges, on a second stream beside reconstruction and

@@ -72,6 +72,7 @@ def lib():
     L.wp_vp8_recon_dev.argtypes = [i32, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]
     L.wp_vp8_loopfilter_dev.argtypes = [i32, vp, vp, vp, vp, sz, vp, vp, vp, vp]
     L.wp_vp8_finish_dev.argtypes = [i32, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp]
+    L.wp_vp8_recon_filter_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, sz, vp]
     L.wp_vp8_finish_range_dev.argtypes = [i32, vp, vp, i32, i32, vp, sz, vp, vp, vp, vp, vp, vp]
     L.wp_yuv420_to_argb_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.wp_vp8_decode_to_argb_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp]

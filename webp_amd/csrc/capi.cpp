@@ -18,6 +18,8 @@ int wpk_launch_vp8_recon(int n, int cus, const wp_vp8_frame* d_frames, const voi
                          uint8_t* d_rtiles, hipStream_t stream);
 int wpk_launch_vp8_filter(int n, int cus, const wp_vp8_frame* d_frames, const uint32_t* d_filt,
                           const uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream);
+int wpk_launch_vp8_recon_filter(int n, int cus, const wp_vp8_frame* d_frames, const void* d_mb, const int16_t* d_coeff,
+                                const uint32_t* d_filt, uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream);
 int wpk_launch_vp8_finish(int n, int chunks, int tile_rows, const wp_vp8_frame* d_frames, const uint8_t* d_rtiles,
                           const uint8_t* d_stiles, int force_unshifted, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
                           const uint8_t* d_alpha, uint8_t* d_argb, hipStream_t stream);
@@ -93,10 +95,10 @@ int check_vp8_work(int n, const wp_vp8_frame* f, const void* d_work, size_t work
 // (kernels/wp_device.h: seq << 12 | macroblocks); a launch therefore takes at most as many frames as keep that count
 // below 2^19 for the smallest grid that can occur (one workgroup per CU) -- far beyond any batch that fits in HBM, but
 // checked rather than assumed.
-int frames_per_launch(int n, const wp_vp8_frame* f) {
+int frames_per_launch(int n, const wp_vp8_frame* f, int phases = 1) {      // phases: how often a workgroup numbers the bands of a frame
     long long max_bands = 1;
     for (int i = 0; i < n; ++i) max_bands = std::max(max_bands, (long long)(f[i].mbh + 3) / 4);
-    const long long per_wg = std::max(1LL, (1LL << 19) / max_bands);
+    const long long per_wg = std::max(1LL, (1LL << 19) / (max_bands * phases));
     return int(std::min<long long>(n, per_wg * std::max(1, g_cus.load(std::memory_order_relaxed))));
 }
 
@@ -221,6 +223,24 @@ int wp_vp8_loopfilter_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd,
     return WP_OK;
 }
 
+int wp_vp8_recon_filter_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint32_t* d_mb, const uint32_t* d_filt,
+                            const int16_t* d_coeff, void* d_work, size_t work_bytes, void* stream) {
+    int rc = ensure_init(); if (rc) return rc;
+    rc = check_vp8_frames(n, fh); if (rc) return rc;
+    if (n == 0) return WP_OK;
+    if (!fd || !d_mb || !d_filt) return fail(WP_ERR_INVALID, "null device pointer");
+    Vp8Work w;
+    rc = check_vp8_work(n, fh, d_work, work_bytes, w); if (rc) return rc;
+    uint8_t* work = static_cast<uint8_t*>(d_work);
+    const int per = frames_per_launch(n, fh, 2);                        // a workgroup numbers the bands of both phases
+    for (int first = 0; first < n; first += per) {
+        const int e = wpk_launch_vp8_recon_filter(std::min(per, n - first), g_cus.load(std::memory_order_relaxed), fd + first, d_mb, d_coeff,
+                                                  d_filt, work, work + w.r_bytes, hipStream_t(stream));
+        if (e) return hip_fail(hipError_t(e), "vp8_recon_filter launch");
+    }
+    return WP_OK;
+}
+
 int wp_vp8_finish_range_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, int first, int count, const void* d_work, size_t work_bytes,
                             uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, const uint8_t* d_alpha, uint8_t* d_argb, void* stream) {
     int rc = ensure_init(); if (rc) return rc;
@@ -271,9 +291,7 @@ int wp_yuv420_to_argb_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd,
 int wp_vp8_decode_to_argb_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint32_t* d_mb, const uint32_t* d_filt,
                               const int16_t* d_coeff, void* d_work, size_t work_bytes, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
                               const uint8_t* d_alpha, uint8_t* d_argb, void* stream) {
-    int rc = wp_vp8_recon_dev(n, fh, fd, d_mb, d_coeff, d_work, work_bytes, nullptr, nullptr, nullptr, stream);
-    if (rc) return rc;
-    rc = wp_vp8_loopfilter_dev(n, fh, fd, d_filt, d_work, work_bytes, nullptr, nullptr, nullptr, stream);
+    int rc = wp_vp8_recon_filter_dev(n, fh, fd, d_mb, d_filt, d_coeff, d_work, work_bytes, stream);      // one launch for both
     if (rc) return rc;
     return wp_vp8_finish_dev(n, fh, fd, d_work, work_bytes, d_y, d_u, d_v, d_alpha, d_argb, stream);
 }

@@ -65,6 +65,12 @@ class DeviceLossyBatch:
         check(lib().wp_vp8_loopfilter_dev(self.b.n, self.b.desc, self.frames.data_ptr(), self.filt.data_ptr(),
                                           work.data_ptr(), self.work_bytes, *self._planes(planes), self._stream()))
 
+    def recon_filter(self, work=None):
+        """Reconstruction and loop filter (workspace R tiles -> S tiles) as one launch."""
+        work = self.work if work is None else work
+        check(lib().wp_vp8_recon_filter_dev(self.b.n, self.b.desc, self.frames.data_ptr(), self.mb.data_ptr(), self.filt.data_ptr(),
+                                            self.coeff.data_ptr(), work.data_ptr(), self.work_bytes, self._stream()))
+
     def finish(self, planes=True, argb=True, work=None, first=0, count=None):
         """Finishing pass of frames [first, first + count) (default: all)."""
         work = self.work if work is None else work
@@ -117,12 +123,13 @@ class LossyPipeline:
     hang once many streams existed in the process (a queue whose barrier packet waits for the other stream's kernel can
     starve that stream when the two share a hardware pipe).  At most `max_in_flight` steps are queued ahead of the GPU."""
 
-    def __init__(self, device="cuda:0", max_in_flight=3, split=0.6, finish_delay_us=40):
+    def __init__(self, device="cuda:0", max_in_flight=3, split=0.6, finish_delay_us=40, one_launch=False):
         self.device = torch.device(device)
         self.s_main = torch.cuda.Stream(self.device)
         self.s_finish = torch.cuda.Stream(self.device)
         self.max_in_flight = max_in_flight
         self.split = split
+        self.one_launch = one_launch    # reconstruction + loop filter as one launch (wp_vp8_recon_filter_dev), the whole finishing pass of the step before beside it
         self.finish_delay_cycles = int(finish_delay_us * 2100)     # torch.cuda._sleep counts clock cycles (~2.1 GHz under load)
         self._queued = []               # events of the steps not yet known to be complete, oldest first
         self._pending = None            # (db, work, planes, argb, filtered event, timing list) of the step whose finishing pass is not enqueued yet
@@ -162,6 +169,31 @@ class LossyPipeline:
         self._k += 1
         prev = self._pending
         marks = {}
+        if self.one_launch:
+            with torch.cuda.stream(self.s_main):
+                if self._phase2_done is not None:
+                    self.s_main.wait_event(self._phase2_done)       # the finishing pass before the one that runs beside this launch
+                marks["r0"] = self._mark(self.s_main, timing)
+                db.recon_filter(work=work)
+                marks["r1"] = self._mark(self.s_main, timing)
+                marks["f0"] = marks["f1"] = marks["r1"]
+                filtered = self._event(self.s_main)
+            done_prev = None
+            if prev is not None:
+                pdb, pwork, pplanes, pargb, pfiltered, ptiming, pmarks = prev
+                with torch.cuda.stream(self.s_finish):
+                    self.s_finish.wait_event(pfiltered)
+                    self._let_persistent_kernel_start_first()
+                    pmarks["c0"] = self._mark(self.s_finish, ptiming)
+                    pdb.finish(pplanes, pargb, work=pwork)
+                    pmarks["c1"] = self._mark(self.s_finish, ptiming)
+                    done_prev = self._event(self.s_finish)
+                self._phase2_done = done_prev
+                self._queued.append(done_prev)
+                if ptiming is not None:
+                    ptiming.append(pmarks)
+            self._pending = (db, work, planes, argb, filtered, timing, marks)
+            return done_prev
         # ---- phase 1 ----
         with torch.cuda.stream(self.s_main):
             if self._phase2_done is not None:
