@@ -192,6 +192,12 @@ def test_workspace_checks():
     with pytest.raises(WebPError, match="workspace too small"):
         check(lib().wp_vp8_recon_dev(db.b.n, db.b.desc, db.frames.data_ptr(), db.mb.data_ptr(), db.coeff.data_ptr(),
                                      db.work.data_ptr(), db.work_bytes - 1, None, None, None, None))
+    with pytest.raises(WebPError, match="workspace too small"):
+        check(lib().wp_vp8_recon_filter_dev(db.b.n, db.b.desc, db.frames.data_ptr(), db.mb.data_ptr(), db.filt.data_ptr(), db.coeff.data_ptr(),
+                                            db.work.data_ptr(), db.work_bytes - 1, None))
+    with pytest.raises(WebPError, match="null device pointer"):
+        check(lib().wp_vp8_recon_filter_dev(db.b.n, db.b.desc, db.frames.data_ptr(), db.mb.data_ptr(), None, db.coeff.data_ptr(),
+                                            db.work.data_ptr(), db.work_bytes, None))
     with pytest.raises(WebPError, match="frame range outside the batch"):
         check(lib().wp_vp8_finish_range_dev(db.b.n, db.b.desc, db.frames.data_ptr(), 1, 2, db.work.data_ptr(), db.work_bytes,
                                             None, None, None, None, db.argb.data_ptr(), None))
