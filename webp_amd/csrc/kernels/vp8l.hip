@@ -39,6 +39,8 @@ __device__ __forceinline__ uint32_t add_px(uint32_t a, uint32_t b) {
 // per-byte floor((a + b) / 2)  (Transform.hx:283-285 avg2)
 __device__ __forceinline__ uint32_t avg_px(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0u); }   // v_lerp_u8: (a + b + 0) >> 1 per byte
 
+struct __attribute__((aligned(4))) Px4 { uint32_t v[4]; };      // four pixels, dword-aligned (rows are not 16-byte aligned in general)
+
 // ---------------------------------------------------------------- pass fusion
 // Each pass over an image costs 8 bytes of HBM traffic per pixel, so the passes libwebp's streams need are folded into
 // the kernels next to them; every kernel decides per frame, from the transform list alone, with the same predicates:
@@ -133,17 +135,27 @@ void vp8l_color_indexing_kernel(const wp_vp8l_frame* __restrict__ frames, int pa
     const int pw = loc.width;                                                // packed row length = nTiles(oldWidth, bits)
     const int bpp = 8 >> bits, xmask = (1 << bits) - 1;
     const uint32_t vmask = (1u << bpp) - 1u;
-    // w, height <= 16384: pixel indices fit in 31 bits; (x, y) advance incrementally (one division per lane, not per pixel)
-    const int total = w * fr.height, stride = int(gridDim.x * blockDim.x);
-    const int qs = stride / w, rs = stride - qs * w;
+    // Four pixels of one row per lane (16-byte stores; the packed source dwords they share are loaded once by the cache).
+    // w, height <= 16384: indices fit in 31 bits; (quad, row) advance incrementally (one division per lane, not per pixel).
+    const int qpr = (w + 3) >> 2, total = qpr * fr.height, stride = int(gridDim.x * blockDim.x);
+    const int qs = stride / qpr, rs = stride - qs * qpr;
     int i = int(blockIdx.x * blockDim.x + threadIdx.x);
-    int y = i / w, x = i - y * w;
-#pragma unroll 4
+    int y = i / qpr, xq = i - y * qpr;
     for (; i < total; i += stride) {
-        const uint32_t g = (src[y * pw + (x >> bits)] >> 8) & 0xff;
-        dst[i] = swizzled(palette[(g >> ((x & xmask) * bpp)) & vmask], sw);
-        x += rs; y += qs;
-        if (x >= w) { x -= w; ++y; }
+        const int x0 = 4 * xq;
+        const uint32_t* srow = src + y * pw;
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = min(x0 + j, w - 1);
+            const uint32_t g = (srow[x >> bits] >> 8) & 0xff;
+            o[j] = swizzled(palette[(g >> ((x & xmask) * bpp)) & vmask], sw);
+        }
+        uint32_t* d = dst + y * w + x0;
+        if (x0 + 4 <= w) { Px4 v; v.v[0] = o[0]; v.v[1] = o[1]; v.v[2] = o[2]; v.v[3] = o[3]; *reinterpret_cast<Px4*>(d) = v; }
+        else { d[0] = o[0]; if (x0 + 1 < w) d[1] = o[1]; if (x0 + 2 < w) d[2] = o[2]; }
+        xq += rs; y += qs;
+        if (xq >= qpr) { xq -= qpr; ++y; }
     }
 }
 
@@ -212,7 +224,6 @@ __device__ __forceinline__ uint32_t predict_px(int mode, uint32_t L, uint32_t T,
     }
 }
 
-struct __attribute__((aligned(4))) Px4 { uint32_t v[4]; };
 // value of the lane above (lane r-1) as one DPP move (wave_shr:1; gfx9 has it) instead of a trip through the LDS
 // crossbar (ds_bpermute): these hand-overs sit on the per-step dependency chain.  Lane 0 gets 0 and never uses it.
 __device__ __forceinline__ uint32_t from_lane_above(uint32_t v) {
