@@ -576,6 +576,52 @@ void alpha_columns_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* al
     for (; y < h; ++y) { acc = (acc + a[(long long)y * w]) & 0xff; a[(long long)y * w] = uint8_t(acc); }
 }
 
+// Horizontal filter, fast path (rows that start dword-aligned): unfiltered[y][x] = sum_{i<=y} raw[i][0] + sum_{1<=j<=x} raw[y][j]
+// (mod 256; :364-376), i.e. a running sum down column 0 and then an independent running sum along every row.
+__device__ __forceinline__ bool alpha_fast_horizontal(const wp_alpha_frame& fr) {
+    return fr.filter == 1 && (fr.width & 3) == 0 && (fr.dst_off & 3) == 0;
+}
+// stage 1: column 0 (one wavefront per frame, 64 rows per round)
+__global__ __launch_bounds__(64)
+void alpha_col0_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* alpha) {
+    const wp_alpha_frame& fr = frames[blockIdx.x];
+    if (!alpha_fast_horizontal(fr)) return;
+    uint8_t* a = alpha + fr.dst_off;
+    const int lane = threadIdx.x, w = fr.width;
+    uint32_t carry = 0;
+    for (int yb = 0; yb < fr.height; yb += 64) {
+        const int y = yb + lane;
+        uint32_t v = y < fr.height ? a[(long long)y * w] : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d); if (lane >= d) v += t; }
+        v = (v + carry) & 0xff;
+        if (y < fr.height) a[(long long)y * w] = uint8_t(v);
+        carry = __shfl(v, 63);
+    }
+}
+// stage 2: one wavefront per row, 256 pixels (a dword per lane) per round
+__global__ __launch_bounds__(256)
+void alpha_hrows_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* alpha) {
+    const wp_alpha_frame& fr = frames[blockIdx.y];
+    if (!alpha_fast_horizontal(fr)) return;
+    const int lane = threadIdx.x & 63, w = fr.width;
+    for (int y = blockIdx.x * 4 + (threadIdx.x >> 6); y < fr.height; y += gridDim.x * 4) {
+        uint32_t* row = reinterpret_cast<uint32_t*>(alpha + fr.dst_off + (long long)y * w);
+        uint32_t carry = 0;
+        for (int xb = 0; xb < w; xb += 256) {
+            const int x = xb + 4 * lane;
+            const uint32_t v = x < w ? row[x >> 2] : 0u;
+            const uint32_t p0 = v & 0xff, p1 = p0 + ((v >> 8) & 0xff), p2 = p1 + ((v >> 16) & 0xff), p3 = p2 + (v >> 24);
+            uint32_t sc = p3;                                                  // inclusive scan of the lanes' totals
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(sc, d); if (lane >= d) sc += t; }
+            const uint32_t e = sc - p3 + carry;                                // everything to the left of this lane's dword
+            if (x < w) row[x >> 2] = ((p0 + e) & 0xff) | ((p1 + e) & 0xff) << 8 | ((p2 + e) & 0xff) << 16 | ((p3 + e) & 0xff) << 24;
+            carry = (__shfl(sc, 63) + carry) & 0xff;
+        }
+    }
+}
+
 // horizontal (1) and gradient (3) filters: one wavefront per frame, sequential over 64-row bands,
 // lane = row, rows skewed by one pixel (row r handles x = s - r): the row above has then just
 // produced its pixel x.  The band's first row reads the previous band's last row from memory in
@@ -584,7 +630,7 @@ __global__ __launch_bounds__(64)
 void alpha_unfilter_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* alpha) {
     const wp_alpha_frame& fr = frames[blockIdx.x];
     const int w = fr.width, h = fr.height, filter = fr.filter;
-    if (filter != 1 && filter != 3) return;
+    if ((filter != 1 && filter != 3) || alpha_fast_horizontal(fr)) return;
     uint8_t* a = alpha + fr.dst_off;
     const int lane = threadIdx.x;
     for (int y0 = 0; y0 < h; y0 += 64) {
@@ -678,6 +724,22 @@ extern "C" int wpk_launch_alpha(int n, const wp_alpha_frame* fh, const wp_alpha_
         for (int first = 0; first < n; first += 65535)
             hipLaunchKernelGGL(alpha_columns_kernel, dim3((max_w + 255) / 256, std::min(65535, n - first)), dim3(256), 0, stream, fd + first, d_alpha);
     }
-    if (f13) hipLaunchKernelGGL(alpha_unfilter_kernel, dim3(n), dim3(64), 0, stream, fd, d_alpha);
+    bool f1 = false, slow = false;
+    int max_h = 1;
+    for (int i = 0; i < n; ++i) {
+        const bool fast = fh[i].filter == 1 && (fh[i].width & 3) == 0 && (fh[i].dst_off & 3) == 0;      // alpha_fast_horizontal
+        f1 = f1 || fast;
+        slow = slow || ((fh[i].filter == 1 || fh[i].filter == 3) && !fast);
+        max_h = std::max(max_h, fh[i].height);
+    }
+    if (f1) {
+        hipLaunchKernelGGL(alpha_col0_kernel, dim3(n), dim3(64), 0, stream, fd, d_alpha);
+        for (int first = 0; first < n; first += 65535) {
+            const int cnt = std::min(65535, n - first);
+            const int gx = std::max(1, std::min((max_h + 3) / 4, std::max(8, 16384 / cnt)));
+            hipLaunchKernelGGL(alpha_hrows_kernel, dim3(gx, cnt), dim3(256), 0, stream, fd + first, d_alpha);
+        }
+    }
+    if (slow) hipLaunchKernelGGL(alpha_unfilter_kernel, dim3(n), dim3(64), 0, stream, fd, d_alpha);
     return int(hipGetLastError());
 }
