@@ -174,6 +174,12 @@ def test_green_only_output_is_the_green_channel():
     pal = rng.integers(0, 256, 4 * 16, dtype=np.uint8)
     cases.append(dict(width=w, height=h, coded_width=pw, pix=pix, transforms=[(3, bits, w, pal)]))
     want.append(oracle.inverse_color_indexing(w, bits, pal, pix, h)[1::4])
+    for (w, h, bits) in ((64, 5, 2), (128, 3, 3), (20, 7, 0), (33, 4, 0)):      # indexing pass writes the green bytes itself: aligned quads, ragged rows, no packing
+        pw = (w + (1 << bits) - 1) >> bits
+        pix = rng.integers(0, 256, 4 * pw * h, dtype=np.uint8)
+        pal = rng.integers(0, 256, 4 * (1 << (8 >> bits)), dtype=np.uint8)
+        cases.append(dict(width=w, height=h, coded_width=pw, pix=pix, transforms=[(3, bits, w, pal)]))
+        want.append(oracle.inverse_color_indexing(w, bits, pal, pix, h)[1::4])
     got = _run_chain(cases, swizzle=2)
     for c, g, e in zip(cases, got, want):
         n = c["width"] * c["height"]

@@ -48,10 +48,11 @@ struct __attribute__((aligned(4))) Px4 { uint32_t v[4]; };      // four pixels, 
 //   * the frame's final pixels (R,G,B,A or rotated to A,R,G,B) are written into the result slab by the predictor kernel
 //     when the predictor is the last transform undone, or the last but a subtract-green (applied on the way out), and by
 //     the colour-indexing kernel when that is the last; the finishing pass then skips the frame.
-// Anything else (and green-only output) takes the general one-pass-per-transform route.
+// Anything else (and green-only output, except from a last colour-indexing pass) takes the general one-pass-per-transform route.
 enum OutputWriter { kOutFinish = 0, kOutPredictor = 1, kOutPredictorSG = 2, kOutIndexing = 3 };
 __device__ __forceinline__ int output_writer(const wp_vp8l_frame& fr, int swizzle) {
-    if (swizzle == WP_SWIZZLE_GREEN || fr.n_transforms == 0) return kOutFinish;
+    if (fr.n_transforms == 0) return kOutFinish;
+    if (swizzle == WP_SWIZZLE_GREEN) return fr.t[0].type == 3 ? kOutIndexing : kOutFinish;      // a palette ALPH image: green bytes straight from the indexing pass
     if (fr.t[0].type == 0) return kOutPredictor;
     if (fr.t[0].type == 2 && fr.n_transforms >= 2 && fr.t[1].type == 0) return kOutPredictorSG;
     if (fr.t[0].type == 3) return kOutIndexing;
@@ -123,12 +124,15 @@ void vp8l_color_indexing_kernel(const wp_vp8l_frame* __restrict__ frames, int pa
     const uint32_t* palette = reinterpret_cast<const uint32_t*>(aux + fr.t[idx].data_off);
     const bool final_out = idx == 0 && output_writer(fr, swizzle) == kOutIndexing;      // the last transform undone: straight into the result slab
     const int sw = final_out ? swizzle : WP_SWIZZLE_NONE;
+    const bool green = sw == WP_SWIZZLE_GREEN;                              // one byte per pixel out
+    uint8_t* const gdst = out + fr.out_off;
     if (bits == 0) {                                                        // in place, whole buffer (:237-248)
         uint32_t* p = const_cast<uint32_t*>(src);
         uint32_t* q = final_out ? reinterpret_cast<uint32_t*>(out + fr.out_off) : p;
         const long long total = (long long)loc.width * fr.height;
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
-            q[i] = swizzled(palette[(p[i] >> 8) & 0xff], sw);
+            if (green) gdst[i] = uint8_t(palette[(p[i] >> 8) & 0xff] >> 8);
+            else q[i] = swizzled(palette[(p[i] >> 8) & 0xff], sw);
         return;
     }
     uint32_t* dst = reinterpret_cast<uint32_t*>(final_out ? out + fr.out_off : tmp + fr.tmp_off);     // new 4*oldWidth*h buffer (:261)
@@ -149,7 +153,16 @@ void vp8l_color_indexing_kernel(const wp_vp8l_frame* __restrict__ frames, int pa
         for (int j = 0; j < 4; ++j) {
             const int x = min(x0 + j, w - 1);
             const uint32_t g = (srow[x >> bits] >> 8) & 0xff;
-            o[j] = swizzled(palette[(g >> ((x & xmask) * bpp)) & vmask], sw);
+            o[j] = swizzled(palette[(g >> ((x & xmask) * bpp)) & vmask], green ? WP_SWIZZLE_NONE : sw);
+        }
+        if (green) {
+            uint8_t* gd = gdst + y * w + x0;
+            const uint32_t g4 = ((o[0] >> 8) & 0xff) | ((o[1] >> 8) & 0xff) << 8 | ((o[2] >> 8) & 0xff) << 16 | ((o[3] >> 8) & 0xff) << 24;
+            if (x0 + 4 <= w && ((fr.out_off + size_t(y) * w + x0) & 3) == 0) *reinterpret_cast<uint32_t*>(gd) = g4;
+            else for (int j = 0; j < 4 && x0 + j < w; ++j) gd[j] = uint8_t(g4 >> (8 * j));
+            xq += rs; y += qs;
+            if (xq >= qpr) { xq -= qpr; ++y; }
+            continue;
         }
         uint32_t* d = dst + y * w + x0;
         if (x0 + 4 <= w) { Px4 v; v.v[0] = o[0]; v.v[1] = o[1]; v.v[2] = o[2]; v.v[3] = o[3]; *reinterpret_cast<Px4*>(d) = v; }
@@ -533,6 +546,7 @@ void alpha_copy_kernel(const wp_alpha_frame* __restrict__ frames, const uint8_t*
     uint8_t* d = alpha + fr.dst_off;
     const long long total = (long long)fr.width * fr.height;
     const bool rgba = fr.src_is_vp8l_rgba != 0;
+    if (!rgba && s == d) return;                       // unfiltering in place: the plane is where it belongs already
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
         d[i] = uint8_t(alpha_src(s, rgba, i));
 }
