@@ -191,7 +191,7 @@ def test_alpha_unfilter_modes(rgba):
     from oracle import oracle
     from webp_amd._lib import AlphaFrame, lib, check
     rng = np.random.default_rng(31)
-    sizes = [(1, 1), (7, 1), (1, 9), (13, 9), (64, 64), (65, 129), (300, 77), (1280, 70)]
+    sizes = [(1, 1), (7, 1), (1, 9), (13, 9), (64, 64), (65, 129), (300, 77), (1280, 70), (40, 600), (131, 321)]      # the last two: more bands than wavefronts
     items = [(w, h, f) for (w, h) in sizes for f in (0, 1, 2, 3)]
     desc = (AlphaFrame * len(items))()
     srcs, so, do, want = [], 0, 0, []

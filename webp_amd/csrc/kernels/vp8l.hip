@@ -636,26 +636,49 @@ void alpha_hrows_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* alph
     }
 }
 
-// horizontal (1) and gradient (3) filters: one wavefront per frame, sequential over 64-row bands,
-// lane = row, rows skewed by one pixel (row r handles x = s - r): the row above has then just
-// produced its pixel x.  The band's first row reads the previous band's last row from memory in
-// 64-byte blocks fetched one block ahead.
-__global__ __launch_bounds__(64)
+// horizontal (1, rows not dword-aligned) and gradient (3) filters: one workgroup of four wavefronts per frame; a wavefront
+// owns a band of 64 rows, lane = row, rows skewed by one pixel (row r handles x = s - r): the row above has then just
+// produced its pixel x.  Bands are pipelined over the wavefronts like the VP8L predictor's: the band's first row reads
+// the last row of the band above from memory, in 64-byte blocks fetched one block ahead, as far as that band has
+// announced it (LDS progress word, workgroup-scope release / acquire).
+constexpr int kAlphaWaves = 4;
+__global__ __launch_bounds__(kAlphaWaves * 64)
 void alpha_unfilter_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* alpha) {
+    __shared__ uint32_t progress[kAlphaWaves];      // ((band + 1) << 15) | pixels of the band's last row that are in memory
     const wp_alpha_frame& fr = frames[blockIdx.x];
     const int w = fr.width, h = fr.height, filter = fr.filter;
     if ((filter != 1 && filter != 3) || alpha_fast_horizontal(fr)) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < kAlphaWaves) progress[threadIdx.x] = 0;
+    __syncthreads();
     uint8_t* a = alpha + fr.dst_off;
-    const int lane = threadIdx.x;
-    for (int y0 = 0; y0 < h; y0 += 64) {
+    const int n_bands = (h + 63) / 64;
+    for (int band = wave; band < n_bands; band += kAlphaWaves) {
+        const int y0 = band * 64;
         const int y = y0 + lane;
         const bool row_ok = y < h;
         const int rows_here = min(64, h - y0);
+        const bool has_above = band > 0, has_below = band + 1 < n_bands;
+        const int prev_wave = (wave + kAlphaWaves - 1) % kAlphaWaves;
         uint8_t* row = a + (long long)(row_ok ? y : 0) * w;
-        const uint8_t* above = a + (long long)(y0 > 0 ? y0 - 1 : 0) * w;      // last row of the previous band (own stores)
-        uint32_t cur = 0, up_prev = 0;
-        uint32_t abuf = (y0 > 0 && lane < w) ? above[lane] : 0u;
-        uint32_t anext = (y0 > 0 && 64 + lane < w) ? above[64 + lane] : 0u;
+        const uint8_t* above = a + (long long)(y0 > 0 ? y0 - 1 : 0) * w;      // last row of the band above
+        uint32_t avail = 0;
+        auto wait_above = [&](uint32_t need) {
+            if (avail < need) {
+                const uint32_t target = (uint32_t(band) << 15) | need;        // the band above announces itself as (band - 1) + 1
+                uint32_t v;
+                while ((v = __hip_atomic_load(&progress[prev_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+                    __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                avail = (v >> 15) == uint32_t(band) ? (v & 0x7fffu) : uint32_t(w);
+            }
+        };
+        uint32_t cur = 0, up_prev = 0, abuf = 0, anext = 0;
+        if (has_above) {
+            wait_above(uint32_t(min(w, 128)));
+            abuf = lane < w ? above[lane] : 0u;
+            anext = 64 + lane < w ? above[64 + lane] : 0u;
+        }
         const int n_steps = w + rows_here - 1;
         for (int s = 0; s < n_steps; ++s) {
             const int x = s - lane;
@@ -664,8 +687,12 @@ void alpha_unfilter_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* a
             if (lane == 0) up = up0;
             if ((s & 63) == 63) {
                 abuf = anext;
-                const int nx = s + 1 + 64 + lane;
-                anext = (y0 > 0 && nx < w) ? above[nx] : 0u;
+                const int nb = s + 1 + 64;                                     // first column of the block after the next
+                anext = 0u;
+                if (has_above && nb < w) {
+                    wait_above(uint32_t(min(w, nb + 64)));
+                    anext = nb + lane < w ? above[nb + lane] : 0u;
+                }
             }
             if (row_ok && x >= 0 && x < w) {
                 const uint32_t v = row[x];
@@ -677,10 +704,12 @@ void alpha_unfilter_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* a
                 row[x] = uint8_t(cur);
                 up_prev = up;
             }
+            if (has_below && (s & 63) == 63) {
+                const int done = s - 63 + 1;                                   // pixels the band's last row (lane 63) has stored
+                if (done > 0) publish_progress(&progress[wave], (uint32_t(band + 1) << 15) | uint32_t(min(done, w)));
+            }
         }
-        // this band's last row must be complete before lane-wide reads of it in the next band
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (has_below) publish_progress(&progress[wave], (uint32_t(band + 1) << 15) | uint32_t(w));
     }
 }
 
@@ -754,6 +783,6 @@ extern "C" int wpk_launch_alpha(int n, const wp_alpha_frame* fh, const wp_alpha_
             hipLaunchKernelGGL(alpha_hrows_kernel, dim3(gx, cnt), dim3(256), 0, stream, fd + first, d_alpha);
         }
     }
-    if (slow) hipLaunchKernelGGL(alpha_unfilter_kernel, dim3(n), dim3(64), 0, stream, fd, d_alpha);
+    if (slow) hipLaunchKernelGGL(alpha_unfilter_kernel, dim3(n), dim3(kAlphaWaves * 64), 0, stream, fd, d_alpha);
     return int(hipGetLastError());
 }
