@@ -78,6 +78,31 @@ def cpu_baseline(paths, budget_s=12.0):
     return out
 
 
+def verify_outputs(db, batch, paths, n_images):
+    """After the timed region: the outputs the last step left in HBM (planes + ARGB) of a sample of frames -- frame 0, the
+    last frame and a run of indices in the batch's second half, i.e. frames that are a persistent workgroup's second or
+    later frame, covering every distinct stream -- against the CPU oracle's decode of the same file.  Returns the number
+    of frames compared; raises on the first difference (a bench line is only printed for bit-exact output)."""
+    import numpy as np
+    from oracle import oracle
+    n = n_images
+    half = n // 2
+    idx = sorted(set([0, n - 1, max(0, half - 1)] + [min(n - 1, half + k) for k in range(len(paths) + 2)] +
+                     [min(n - 1, half + (n - half) * k // 6) for k in range(1, 6)]))
+    want = {}
+    for i in idx:
+        s = i % len(paths)
+        if s not in want:
+            want[s] = oracle.decode(open(paths[s], "rb").read())
+        w = want[s]
+        y, u, v = db.planes(i)
+        if not (np.array_equal(y, w["y"]) and np.array_equal(u, w["u"]) and np.array_equal(v, w["v"])):
+            raise SystemExit("bench.py: YUV planes of frame %d (%s) differ from the oracle" % (i, os.path.basename(paths[s])))
+        if not np.array_equal(db.argb_of(i), w["to_argb"]):
+            raise SystemExit("bench.py: ARGB of frame %d (%s) differs from the oracle" % (i, os.path.basename(paths[s])))
+    return {"count": len(idx), "indices": idx, "against": "oracle.decode (planes + ARGB, bit-exact)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +212,7 @@ def main():
             db.decode_to_argb()
         torch.cuda.synchronize()
         serial_ms = 1e3 * (time.perf_counter() - ts0) / args.steps
+    verified = verify_outputs(db, batch, paths, args.images) if rank == 0 else None
     in_bytes = batch.input_bytes()
     yuv_bytes = 384 * n_mb
     argb_bytes = 4 * px_per_step
@@ -244,6 +270,7 @@ def main():
                                           "2 HIP streams, 2 phases: finishing pass of step k (first %d %% of the frames) beside reconstruction of step k+1, "
                                           "the rest beside its loop filter; workspaces alternate" % round(100 * args.split),
                        "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 4)},
+            "verified_frames": None if verified is None else verified["count"], "verified": verified,
             "roofline": roofline}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(paths)

@@ -113,6 +113,10 @@ int wp_init(int device);                 /* selects the HIP device for the calli
 int wp_shutdown(void);
 int wp_last_error(char* buf, int cap);   /* copies the calling thread's last error message */
 int wp_device_count(void);
+/* Test hook (no counterpart in the reference): caps the number of frames the wavefront-scheduled lossy kernels take per
+ * launch, so that the split the library makes for batches beyond its band-sequence range (2^19 bands per persistent
+ * workgroup, i.e. > 500 000 frames) can be exercised with a small batch.  0 restores the default. */
+int wp_debug_set_frames_per_launch(int frames);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Device-resident batch entry points                                                           */

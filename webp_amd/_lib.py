@@ -67,6 +67,7 @@ def lib():
     L = ctypes.CDLL(SO_PATH)
     vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     L.wp_init.argtypes = [i32]
+    L.wp_debug_set_frames_per_launch.argtypes = [i32]
     L.wp_last_error.argtypes = [ctypes.c_char_p, i32]
     L.wp_vp8_plan.argtypes = [i32, vp, ctypes.POINTER(ctypes.c_uint64)]
     L.wp_vp8_recon_dev.argtypes = [i32, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]

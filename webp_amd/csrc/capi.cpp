@@ -37,6 +37,7 @@ namespace {
 
 thread_local std::string g_error;
 std::atomic<int> g_cus{0};      // compute units of the device (all devices of a node are the same part)
+std::atomic<int> g_launch_cap{0};   // wp_debug_set_frames_per_launch: test hook, 0 = off
 
 int fail(int code, const std::string& msg) { g_error = msg; return code; }
 int hip_fail(hipError_t e, const char* what) { return fail(WP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
@@ -99,7 +100,10 @@ int frames_per_launch(int n, const wp_vp8_frame* f, int phases = 1) {      // ph
     long long max_bands = 1;
     for (int i = 0; i < n; ++i) max_bands = std::max(max_bands, (long long)(f[i].mbh + 3) / 4);
     const long long per_wg = std::max(1LL, (1LL << 19) / (max_bands * phases));
-    return int(std::min<long long>(n, per_wg * std::max(1, g_cus.load(std::memory_order_relaxed))));
+    long long per = std::min<long long>(n, per_wg * std::max(1, g_cus.load(std::memory_order_relaxed)));
+    const int cap = g_launch_cap.load(std::memory_order_relaxed);
+    if (cap > 0) per = std::min<long long>(per, cap);
+    return int(std::max(1LL, per));
 }
 
 struct FinishGeom { int chunks = 1, rows = 1; };
@@ -154,6 +158,12 @@ int wp_init(int device) {
 }
 
 int wp_shutdown(void) { return WP_OK; }
+
+int wp_debug_set_frames_per_launch(int frames) {
+    if (frames < 0) return fail(WP_ERR_INVALID, "negative frame count");
+    g_launch_cap.store(frames, std::memory_order_relaxed);
+    return WP_OK;
+}
 
 int wp_last_error(char* buf, int cap) {
     if (!buf || cap <= 0) return int(g_error.size());
