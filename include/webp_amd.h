@@ -187,6 +187,20 @@ int wp_vp8_decode_to_argb_dev(int n, const wp_vp8_frame* frames_host, const wp_v
                               uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
                               const uint8_t* d_alpha, uint8_t* d_argb, void* stream);
 
+/* wp_vp8_decode_to_argb_dev for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc) and therefore cannot bring a workspace.  No counterpart in the reference.  The
+ * R / S tiles live in a static device array of WP_STATIC_WORK_BYTES that every GPU the library runs on holds from the
+ * moment the library is loaded until the process ends; the call allocates and frees nothing, on the device or through
+ * any library.  stile_base in the descriptors must come from wp_vp8_plan as usual; a batch whose workspace (what
+ * wp_vp8_plan reports: ~768 bytes per macroblock, 6.4 MB per 1080p frame) exceeds WP_STATIC_WORK_BYTES is refused with
+ * WP_ERR_UNSUPPORTED.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams,
+ * two threads) race -- serialise them.  Results are identical to wp_vp8_decode_to_argb_dev's. */
+#define WP_STATIC_WORK_BYTES (64u << 20)
+int wp_vp8_decode_to_argb_static_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
+                                     const uint32_t* d_mb, const uint32_t* d_filt, const int16_t* d_coeff,
+                                     uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
+                                     const uint8_t* d_alpha, uint8_t* d_argb, void* stream);
+
 /* VP8L inverse transform chain + RGBA->ARGB swizzle.  Replaces Transform.hx inversePredictor /
  * inverseCrossColor / inverseSubtractGreen / inverseColorIndexing, the driver loop
  * Vp8LDecoder.hx:395-401 and the swizzle WebPDecoder.hx:109-123.

@@ -77,6 +77,7 @@ def lib():
     L.wp_vp8_finish_range_dev.argtypes = [i32, vp, vp, i32, i32, vp, sz, vp, vp, vp, vp, vp, vp]
     L.wp_yuv420_to_argb_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.wp_vp8_decode_to_argb_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp]
+    L.wp_vp8_decode_to_argb_static_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.wp_vp8l_inverse_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, vp]
     L.wp_alpha_unfilter_dev.argtypes = [i32, vp, vp, vp, vp, vp]
     L.wp_vp8_decode_to_argb.argtypes = [i32, vp, vp, sz, vp, vp, sz, vp, vp, vp, vp, vp]

@@ -33,6 +33,11 @@ int wpk_launch_alpha(int n, const wp_alpha_frame* frames_host, const wp_alpha_fr
                      hipStream_t stream);
 }
 
+// Workspace of wp_vp8_decode_to_argb_static_dev, the entry point that allocates nothing: device memory that exists from
+// the moment the code object is loaded.  In host code this name is only a handle for hipGetSymbolAddress -- every use of
+// the memory goes through the per-device address resolved by static_scratch() below.
+static __device__ __align__(256) unsigned char scratch[WP_STATIC_WORK_BYTES];
+
 namespace {
 
 thread_local std::string g_error;
@@ -46,6 +51,24 @@ int hip_fail(hipError_t e, const char* what) { return fail(WP_ERR_HIP, std::stri
 int ensure_init() {
     if (g_cus.load(std::memory_order_relaxed) > 0) return WP_OK;
     return wp_init(-1);
+}
+
+// Address of `scratch` on the CURRENT device (every GPU holds its own copy of the array at its own address): resolved once
+// per device -- by wp_init, or by the first static call on a device wp_init was never called for -- and kept.
+constexpr int kMaxDevices = 64;
+std::atomic<void*> g_scratch_ptr[kMaxDevices];
+int static_scratch(void** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(WP_ERR_UNSUPPORTED, "device index beyond the static workspace table");
+    void* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(WP_ERR_HIP, "hipGetSymbolAddress returned a null address for the static workspace");
+        g_scratch_ptr[dev].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return WP_OK;
 }
 
 int check_vp8_frames(int n, const wp_vp8_frame* f) {
@@ -154,7 +177,8 @@ int wp_init(int device) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     g_cus.store(prop.multiProcessorCount, std::memory_order_relaxed);
-    return WP_OK;
+    void* sp = nullptr;
+    return static_scratch(&sp);             // set-up is where the static workspace's address on this device is looked up
 }
 
 int wp_shutdown(void) { return WP_OK; }
@@ -304,6 +328,22 @@ int wp_vp8_decode_to_argb_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame*
     int rc = wp_vp8_recon_filter_dev(n, fh, fd, d_mb, d_filt, d_coeff, d_work, work_bytes, stream);      // one launch for both
     if (rc) return rc;
     return wp_vp8_finish_dev(n, fh, fd, d_work, work_bytes, d_y, d_u, d_v, d_alpha, d_argb, stream);
+}
+
+int wp_vp8_decode_to_argb_static_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint32_t* d_mb, const uint32_t* d_filt,
+                                     const int16_t* d_coeff, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
+                                     const uint8_t* d_alpha, uint8_t* d_argb, void* stream) {
+    int rc = ensure_init(); if (rc) return rc;
+    rc = check_vp8_frames(n, fh); if (rc) return rc;
+    const Vp8Work w = vp8_work(n, fh);
+    if (w.total > size_t(WP_STATIC_WORK_BYTES))
+        return fail(WP_ERR_UNSUPPORTED, "batch needs a workspace of " + std::to_string(w.total) + " bytes, the static one holds " +
+                    std::to_string(size_t(WP_STATIC_WORK_BYTES)) + " (WP_STATIC_WORK_BYTES): use wp_vp8_decode_to_argb_dev with a caller workspace");
+    void* work = nullptr;
+    rc = static_scratch(&work); if (rc) return rc;
+    // Nothing in the workspace has to start at zero: every tile byte the finishing pass uses is written by this call's
+    // reconstruction / loop filter first (what an earlier, larger call left behind is never read).
+    return wp_vp8_decode_to_argb_dev(n, fh, fd, d_mb, d_filt, d_coeff, work, size_t(WP_STATIC_WORK_BYTES), d_y, d_u, d_v, d_alpha, d_argb, stream);
 }
 
 int wp_vp8l_inverse_dev(int n, const wp_vp8l_frame* fh, const wp_vp8l_frame* fd, uint8_t* d_pix, const uint8_t* d_aux,
