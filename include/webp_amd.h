@@ -143,23 +143,25 @@ int wp_vp8_recon_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame*
 
 /* Loop filter for n frames.  Replaces simpleFilter / normalFilter (vp8/Vp8Decoder.hx:417-486) and
  * vp8/Filter.hx.  d_filt: one filter record per MB (same indexing as d_mb).
- * d_y/d_u/d_v NULL: filters the R tiles left in the workspace by wp_vp8_recon_dev into S tiles.
+ * d_y/d_u/d_v NULL: filters the R tiles left in the workspace by wp_vp8_recon_dev into S tiles (all frames; frames with
+ * filter_type == 0 are re-tiled unchanged).
  * d_y/d_u/d_v given: filters those row-major planes in place (tile -> filter -> untile). */
 int wp_vp8_loopfilter_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
                           const uint32_t* d_filt, void* d_work, size_t work_bytes,
                           uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, void* stream);
 
-/* wp_vp8_recon_dev followed by wp_vp8_loopfilter_dev (workspace variants) as ONE launch: each persistent
- * workgroup reconstructs its frames and then filters the same frames, so workgroups whose frames were
- * cheap to reconstruct are already filtering while others still reconstruct.  Same results, same
- * workspace contents afterwards (R tiles, and S tiles of the frames with a loop filter). */
+/* wp_vp8_recon_dev followed by wp_vp8_loopfilter_dev (workspace variants) as ONE kernel that reconstructs and
+ * filters macroblock by macroblock: the reconstructed pixels stay on chip (no R tiles are written or read back;
+ * the R region of the workspace only carries 32-byte edge records between bands and holds no tiles afterwards).
+ * Same results, same S tiles afterwards. */
 int wp_vp8_recon_filter_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
                             const uint32_t* d_mb, const uint32_t* d_filt, const int16_t* d_coeff,
                             void* d_work, size_t work_bytes, void* stream);
 
 /* Finishing pass: workspace tiles -> row-major MB-padded planes (ImageData.Yuv420, Vp8Decoder.ensureImg
- * geometry; optional) and tightly packed A,R,G,B (Tools.toArgb, Tools.hx:6-48; optional).  Frames with
- * filter_type == 0 are taken from the R tiles, all others from the S tiles. */
+ * geometry; optional) and tightly packed A,R,G,B (Tools.toArgb, Tools.hx:6-48; optional).  Reads the S tiles, which
+ * wp_vp8_loopfilter_dev and wp_vp8_recon_filter_dev write for every frame of the batch (frames whose loop filter is off
+ * are re-tiled unchanged). */
 int wp_vp8_finish_dev(int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
                       const void* d_work, size_t work_bytes, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
                       const uint8_t* d_alpha, uint8_t* d_argb, void* stream);

@@ -238,9 +238,6 @@ int wp_vp8_loopfilter_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd,
     Vp8Work w;
     rc = check_vp8_work(n, fh, d_work, work_bytes, w); if (rc) return rc;
     uint8_t* work = static_cast<uint8_t*>(d_work);
-    bool any = false;
-    for (int i = 0; i < n; ++i) any = any || fh[i].filter_type != 0;
-    if (!any) return WP_OK;
     if (planes) {
         for (int first = 0; first < n; first += 65535) {
             const int cnt = std::min(65535, n - first);
@@ -266,7 +263,7 @@ int wp_vp8_recon_filter_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* f
     Vp8Work w;
     rc = check_vp8_work(n, fh, d_work, work_bytes, w); if (rc) return rc;
     uint8_t* work = static_cast<uint8_t*>(d_work);
-    const int per = frames_per_launch(n, fh, 2);                        // a workgroup numbers the bands of both phases
+    const int per = frames_per_launch(n, fh);
     for (int first = 0; first < n; first += per) {
         const int e = wpk_launch_vp8_recon_filter(std::min(per, n - first), g_cus.load(std::memory_order_relaxed), fd + first, d_mb, d_coeff,
                                                   d_filt, work, work + w.r_bytes, hipStream_t(stream));

@@ -43,11 +43,11 @@ void vp8_filter_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, co
     for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
         const wp_vp8_frame fr = frames[f];
         const int n_bands = (fr.mbh + kBandRows - 1) / kBandRows;
-        if (fr.filter_type == 0) { seq += uint32_t(n_bands); continue; }      // filterHeader.level == 0 (Vp8Decoder.hx:365)
         for (int band = 0; band < n_bands; ++band) {
             const uint32_t q = seq + uint32_t(band);
             if (int(q % kFilterWaves) != wave) continue;
-            if (fr.filter_type == 1) filter_band<kFilterWaves, true>(fr, band, n_bands, q, q - 1, wave, progress, lds_all[wave], filt, Rp, Sp);
+            // filterHeader.level == 0 (Vp8Decoder.hx:365): no filtering, the frame is only re-tiled
+            if (fr.filter_type != 2) filter_band<kFilterWaves, true>(fr, band, n_bands, q, q - 1, wave, progress, lds_all[wave], filt, Rp, Sp, fr.filter_type == 0);
             else filter_band<kFilterWaves, false>(fr, band, n_bands, q, q - 1, wave, progress, lds_all[wave], filt, Rp, Sp);
         }
         seq += uint32_t(n_bands);

@@ -117,10 +117,11 @@ __device__ __forceinline__ void filter_line(int (&v)[N], bool mb_edge, bool inne
 
 // One band.  `q` is the band's sequence number in this workgroup, `q_prev` that of the band above (band > 0), `progress`
 // the workgroup's LDS progress words (one per wavefront, W of them).  The caller has made sure that the band's R tiles
-// are complete and visible.
+// are complete and visible.  off: the frame's loop filter is off (filterHeader.level == 0): every record counts as level 0,
+// so the pass only re-tiles the frame (R tiles -> shifted S tiles, which is what the finishing pass reads).
 template <int W, bool SIMPLE>
 __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, int n_bands, uint32_t q, uint32_t q_prev, int wave, uint32_t* progress,
-                                            FilterWaveLds& lds, const uint32_t* __restrict__ filt, const uint8_t* __restrict__ Rp, uint8_t* Sp) {
+                                            FilterWaveLds& lds, const uint32_t* __restrict__ filt, const uint8_t* __restrict__ Rp, uint8_t* Sp, bool off = false) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4;
     const int l = lane & 15;
@@ -162,7 +163,7 @@ __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, in
     if (row_ok && g == 0) {
         nx_y = ld_nt(reinterpret_cast<const uint4*>(rrow + 16 * l));
         nx_c = ld_nt(reinterpret_cast<const uint2*>(rrow + kTileCb + 8 * l));
-        nx_fp = frow[0];
+        nx_fp = off ? 0u : frow[0];
         if (top_lane) { nx_ty = *reinterpret_cast<const uint2*>(trow_y); nx_tc = *reinterpret_cast<const uint32_t*>(trow_c); }
     }
     settle(nx_y); settle(nx_ty); settle(nx_c); settle(nx_tc); settle(nx_fp);
@@ -182,7 +183,7 @@ __device__ __forceinline__ void filter_band(const wp_vp8_frame& fr, int band, in
             const uint32_t o = uint32_t(x + 1) * uint32_t(kTileBytes);      // 32-bit offset inside the row (mbw <= 1024)
             nx_y = ld_nt(reinterpret_cast<const uint4*>(rrow + o + 16 * l));
             nx_c = ld_nt(reinterpret_cast<const uint2*>(rrow + o + kTileCb + 8 * l));
-            nx_fp = frow[x + 1];
+            nx_fp = off ? 0u : frow[x + 1];
             if (top_lane) { nx_ty = *reinterpret_cast<const uint2*>(trow_y + o); nx_tc = *reinterpret_cast<const uint32_t*>(trow_c + o); }
         }
 

@@ -5,8 +5,9 @@
 // Pure streaming.  A workgroup produces 256 output columns x 16 rows: it parks the 16 (or, for shifted tiles,
 // 17) horizontally adjacent source tiles (6.4 KB, contiguous in memory) in LDS and writes rows: a wavefront emits
 // 1 KB of contiguous ARGB (256 pixels of one row), 256 B of luma or 128 B of chroma per instruction, all starting
-// on 128-byte boundaries of the row (no cache line is shared between workgroups).  Frames whose loop filter is off are read from the
-// R tiles (no shift), all others from the S tiles (shift 8 luma / 4 chroma).
+// on 128-byte boundaries of the row (no cache line is shared between workgroups).  Frames are read from the S tiles (shift 8 luma /
+// 4 chroma: what the loop filter and the one-kernel path leave, also for frames whose loop filter is off) or, on request,
+// from the R tiles (no shift: the unfiltered planes wp_vp8_recon_dev can return).
 #include "wp_device.h"
 #include "wp_convert.h"
 
@@ -32,7 +33,7 @@ void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* _
     __shared__ uint4 tiles4[kFinishTiles * kTileBytes / 16];
     const wp_vp8_frame& fr = frames[blockIdx.z];
     const int mbw = fr.mbw, mbh = fr.mbh, width = fr.width, height = fr.height;
-    const bool shifted = fr.filter_type != 0 && !force_unshifted;
+    const bool shifted = !force_unshifted;
     const int shift = shifted ? kFiltShift : 0;
     const int ntx = mbw + (shifted ? 1 : 0), nty = mbh + (shifted ? 1 : 0);
     const int ty = blockIdx.y, c0 = blockIdx.x * kFinishCols;     // output columns c0 .. c0+255
