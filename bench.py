@@ -160,7 +160,11 @@ def main():
                 pipe.submit(db, timing=timing)
             elif timing is None:
                 db.decode_to_argb()
-            else:                                    # the fused call's three launches, staged so that events fit between them
+            elif args.one_launch:                    # one kernel for reconstruction + loop filter, then the finishing pass
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record(); db.recon_filter(); ev[1].record(); db.finish(); ev[2].record()
+                timing.append((ev[0], ev[1], ev[1], ev[1], ev[1], ev[2]))
+            else:                                    # three launches, staged so that events fit between them
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
                 ev[0].record(); db.recon(planes=False); ev[1].record(); db.loopfilter(planes=False); ev[2].record(); db.finish(); ev[3].record()
                 timing.append((ev[0], ev[1], ev[1], ev[2], ev[2], ev[3]))
@@ -220,7 +224,7 @@ def main():
            "vp8_filter_kernel": batch.filt.nbytes + 2 * yuv_bytes,
            "vp8_finish_kernel": 2 * yuv_bytes + argb_bytes}       # tiles in, row-major planes + ARGB out
     times = {"vp8_recon_kernel": t_recon, "vp8_filter_kernel": t_filter, "vp8_finish_kernel": t_conv}
-    if pipe is not None and args.one_launch:         # reconstruction + loop filter are one kernel: packed inputs in, S tiles out
+    if args.one_launch:         # reconstruction + loop filter are one kernel: packed inputs in, S tiles out
         alg = {"vp8_recon_filter_kernel": in_bytes + yuv_bytes, "vp8_finish_kernel": alg["vp8_finish_kernel"]}
         times = {"vp8_recon_filter_kernel": t_recon, "vp8_finish_kernel": t_conv}
     dom = max(times, key=times.get)

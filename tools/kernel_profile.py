@@ -29,3 +29,10 @@ db.loopfilter(planes=False); torch.cuda.synchronize()
 L.wp_debug_profile_filter(buf, 0)
 print("== filter")
 show(["0 wait+prefetch", "1 tile fill", "2 V edges", "3 H edges", "4 publish", "5 emit+handdown", "6", "7", "8 loop top", "9 band start"])
+
+db.recon_filter(); torch.cuda.synchronize()
+L.wp_debug_profile_mb(buf, 1)
+db.recon_filter(); torch.cuda.synchronize()
+L.wp_debug_profile_mb(buf, 0)
+print("== one-kernel path (vp8_mb_kernel)")
+show(["0 wait+above", "1 residual+fetch", "2 prediction", "3 hand-on+copy", "4 V+H edges", "5 publish", "6 emit+handdown", "7", "8 loop top", "9 band start"])

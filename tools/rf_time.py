@@ -1,14 +1,17 @@
+"""One-kernel reconstruction + loop filter (wp_vp8_recon_filter_dev) against the two launches: parity of the finished
+outputs and time.  python tools/rf_time.py [images] [pattern]"""
 import sys, os, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-files, batch, db, paths, _ = bench.build_batch(n, "lossy1080_*.webp", "cuda:0")
-db.decode_to_argb(); torch.cuda.synchronize()
+pattern = sys.argv[2] if len(sys.argv) > 2 else "lossy1080_*.webp"
+files, batch, db, paths, _ = bench.build_batch(n, pattern, "cuda:0")
+db.recon(planes=False); db.loopfilter(planes=False); db.finish(); torch.cuda.synchronize()
 ref = [t.clone() for t in (db.argb, db.y, db.u, db.v)]
 for t in (db.argb, db.y, db.u, db.v): t.zero_()
 db.recon_filter(); db.finish(); torch.cuda.synchronize()
 ok = all(torch.equal(a, b) for a, b in zip((db.argb, db.y, db.u, db.v), ref))
-print("one-launch recon+filter equals staged:", ok, flush=True)
+print("one-kernel recon+filter equals staged:", ok, flush=True)
 def t(fn, reps=10):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

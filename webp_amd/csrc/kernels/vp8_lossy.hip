@@ -47,3 +47,18 @@ extern "C" int wpk_launch_vp8_recon_filter(int n, int cus, const wp_vp8_frame* d
                        n, d_frames, reinterpret_cast<const uint4*>(d_mb), d_coeff, d_filt, d_rtiles, d_stiles);
     return int(hipGetLastError());
 }
+
+#ifdef WP_PROFILE
+extern "C" int wp_debug_profile_mb(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(wpk::wp_prof), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(wpk::wp_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
+// Tuning aid: resident workgroups per CU the runtime computes for the kernel (registers, LDS).
+extern "C" int wp_debug_mb_occupancy(void) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wpk::vp8_mb_kernel, wpk::kMbWaves * wpk::kWave, 0) != hipSuccess) return -1;
+    return n;
+}
