@@ -115,9 +115,11 @@ def main():
     ap.add_argument("--serial", action="store_true", help="one stream per step, no overlap between steps (kernel times as when each runs alone)")
     ap.add_argument("--split", type=float, default=0.6, help="share of a step's frames whose finishing pass runs beside the next reconstruction (the rest: beside the next loop filter)")
     ap.add_argument("--finish-delay-us", type=float, default=40.0, help="how long a finishing pass is held back so that the persistent kernel of its phase is dispatched first")
-    ap.add_argument("--one-launch", action="store_true", help="reconstruction + loop filter as one launch, the whole finishing pass of the step before beside it")
+    ap.add_argument("--two-phase", action="store_true", help="round-1 schedule: reconstruction and loop filter as two kernels (R tiles through HBM), the finishing pass of the step before split over both")
+    ap.add_argument("--workspaces", type=int, default=2, help="tile workspaces the pipelined steps rotate through")
     ap.add_argument("--alone", action="store_true", help="after the timed region also time the single-stream fused call (config.serial_ms_per_step)")
     args = ap.parse_args()
+    args.one_launch = not args.two_phase             # default: vp8_mb_kernel (reconstruction + loop filter, one kernel) with the finishing pass of the step before beside it
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,9 +150,10 @@ def main():
         torch.cuda.synchronize()
 
     from webp_amd.device import LossyPipeline
-    pipe = None if args.serial else LossyPipeline(device, split=args.split, finish_delay_us=args.finish_delay_us, one_launch=args.one_launch)
+    pipe = None if args.serial else LossyPipeline(device, split=args.split, finish_delay_us=args.finish_delay_us, one_launch=args.one_launch, workspaces=args.workspaces)
     if pipe is not None:
-        db.second_workspace()                        # allocated here, not by the first odd step inside the timed region
+        for k in range(args.workspaces):
+            db.workspace(k)                          # allocated here, not inside the timed region
 
     marks = []                                       # per step: timing events around each kernel, on its launch stream
 
@@ -225,8 +228,8 @@ def main():
            "vp8_finish_kernel": 2 * yuv_bytes + argb_bytes}       # tiles in, row-major planes + ARGB out
     times = {"vp8_recon_kernel": t_recon, "vp8_filter_kernel": t_filter, "vp8_finish_kernel": t_conv}
     if args.one_launch:         # reconstruction + loop filter are one kernel: packed inputs in, S tiles out
-        alg = {"vp8_recon_filter_kernel": in_bytes + yuv_bytes, "vp8_finish_kernel": alg["vp8_finish_kernel"]}
-        times = {"vp8_recon_filter_kernel": t_recon, "vp8_finish_kernel": t_conv}
+        alg = {"vp8_mb_kernel": in_bytes + yuv_bytes, "vp8_finish_kernel": alg["vp8_finish_kernel"]}
+        times = {"vp8_mb_kernel": t_recon, "vp8_finish_kernel": t_conv}
     dom = max(times, key=times.get)
     achieved = alg[dom] / (times[dom] * 1e-3) / 1e9                    # bytes per step / time per step = bytes per launch / time per launch
     launches = finish_per_step if dom == "vp8_finish_kernel" else 1.0
@@ -234,7 +237,7 @@ def main():
     # (tools/pmc.sh + tools/pmc_traffic.list), committed under profiles/; scaled if --images differs from that run.
     traffic = None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json" if args.one_launch else "r01_traffic.json")))
         traffic = int(tj["kernels"][dom]["hbm_bytes"] * args.images / tj["images_per_launch"] / launches)
     except Exception:
         pass
@@ -271,8 +274,9 @@ def main():
                        "macroblocks_per_gpu": n_mb, "coeff_blocks_per_mb": round(batch.n_coeff_blocks / max(n_mb, 1), 3),
                        "host_parse_ms_per_image": round(1e3 * t_parse, 2),
                        "step_pipelining": "none (--serial)" if pipe is None else
-                                          "2 HIP streams, 2 phases: finishing pass of step k (first %d %% of the frames) beside reconstruction of step k+1, "
-                                          "the rest beside its loop filter; workspaces alternate" % round(100 * args.split),
+                                          ("2 HIP streams: finishing pass of step k beside the reconstruction + loop filter kernel of step k+1; 2 workspaces alternate" if args.one_launch else
+                                           "2 HIP streams, 2 phases: finishing pass of step k (first %d %% of the frames) beside reconstruction of step k+1, "
+                                           "the rest beside its loop filter; workspaces alternate" % round(100 * args.split)),
                        "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 4)},
             "verified_frames": None if verified is None else verified["count"], "verified": verified,
             "roofline": roofline}

@@ -133,7 +133,7 @@ struct FinishGeom { int chunks = 1, rows = 1; };
 FinishGeom finish_geom(int n, const wp_vp8_frame* f) {
     FinishGeom g;
     for (int i = 0; i < n; ++i) {
-        g.chunks = std::max(g.chunks, (f[i].mbw + 15) / 16);      // 256 output columns per workgroup
+        g.chunks = std::max(g.chunks, (f[i].mbw + 7) / 8);        // 128 output columns per workgroup (kernels/vp8_finish_chunk.h)
         g.rows = std::max(g.rows, f[i].mbh + 1);
     }
     return g;
@@ -267,7 +267,7 @@ int wp_vp8_recon_filter_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* f
     for (int first = 0; first < n; first += per) {
         const int e = wpk_launch_vp8_recon_filter(std::min(per, n - first), g_cus.load(std::memory_order_relaxed), fd + first, d_mb, d_coeff,
                                                   d_filt, work, work + w.r_bytes, hipStream_t(stream));
-        if (e) return hip_fail(hipError_t(e), "vp8_recon_filter launch");
+        if (e) return hip_fail(hipError_t(e), "vp8_mb launch");
     }
     return WP_OK;
 }
@@ -322,7 +322,7 @@ int wp_yuv420_to_argb_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd,
 int wp_vp8_decode_to_argb_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint32_t* d_mb, const uint32_t* d_filt,
                               const int16_t* d_coeff, void* d_work, size_t work_bytes, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
                               const uint8_t* d_alpha, uint8_t* d_argb, void* stream) {
-    int rc = wp_vp8_recon_filter_dev(n, fh, fd, d_mb, d_filt, d_coeff, d_work, work_bytes, stream);      // one launch for both
+    int rc = wp_vp8_recon_filter_dev(n, fh, fd, d_mb, d_filt, d_coeff, d_work, work_bytes, stream);      // one kernel for both
     if (rc) return rc;
     return wp_vp8_finish_dev(n, fh, fd, d_work, work_bytes, d_y, d_u, d_v, d_alpha, d_argb, stream);
 }

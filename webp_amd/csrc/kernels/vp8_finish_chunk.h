@@ -1,0 +1,112 @@
+// Finishing pass of the lossy path, one chunk: 128 output columns x one tile row (16 luma rows) of one frame, from the
+// 8 (or, for shifted tiles, 9) horizontally adjacent source tiles -- parked in LDS by the workgroup -- to the row-major
+// Y/U/V planes (what ImageData.Yuv420 carries, Vp8Decoder.ensureImg geometry) and tightly packed A,R,G,B (Tools.toArgb,
+// Tools.hx:6-48).  Chunks are 128 columns (3.4 KB of LDS) so that two finishing workgroups fit into the 8 KB of LDS two
+// workgroups of the one-kernel reconstruction + loop filter leave on a CU: the pass is memory-bound, that kernel
+// issue-bound, and callers that pipeline batches run them side by side (webp_amd/device.py LossyPipeline).
+#pragma once
+#include "wp_device.h"
+#include "wp_convert.h"
+
+// Everything this pass touches is used exactly once: non-temporal accesses keep it out of the way of the tiles and
+// coefficient blocks that the wavefront-scheduled code re-reads through L2.
+#ifdef WP_FINISH_NO_NT
+#define WP_NT_LOAD(p) (*(p))
+#define WP_NT_STORE(p, v) (*(p) = (v))
+#else
+#define WP_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define WP_NT_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#endif
+
+namespace wpk {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kFinishCols = 128;                       // output luma columns per chunk
+constexpr int kFinishTiles = kFinishCols / 16 + 1;      // source tiles that can overlap them
+constexpr int kFinishLdsBytes = kFinishTiles * kTileBytes;
+
+// t: thread index in the workgroup of 256 (8 row pairs x 32 pixel quads); tiles4: kFinishLdsBytes of LDS.
+__device__ __forceinline__ void finish_chunk(const wp_vp8_frame& fr, int ty, int c0, int t, uint4* tiles4,
+                                             const uint8_t* __restrict__ Rp, const uint8_t* __restrict__ Sp, bool shifted,
+                                             uint8_t* Yp, uint8_t* Up, uint8_t* Vp, const uint8_t* __restrict__ Ap, uint8_t* out) {
+    const int mbw = fr.mbw, mbh = fr.mbh, width = fr.width, height = fr.height;
+    const int shift = shifted ? kFiltShift : 0;
+    const int ntx = mbw + (shifted ? 1 : 0);
+    const int tx0 = c0 >> 4;                                      // (c0 + shift) >> 4: first source tile
+    const int nt = min(shifted ? kFinishTiles : kFinishTiles - 1, ntx - tx0);
+    const uint8_t* src = (shifted ? Sp + size_t(fr.stile_base) * kTileBytes : Rp + size_t(fr.mb_base) * kTileBytes)
+                       + (size_t(ty) * ntx + tx0) * kTileBytes;
+    if (t < nt * (kTileBytes / 16)) { const int i = t; const u32x4 v = WP_NT_LOAD(reinterpret_cast<const u32x4*>(src) + i); tiles4[i] = make_uint4(v.x, v.y, v.z, v.w); }
+    __syncthreads();
+    const uint32_t* tiles32 = reinterpret_cast<const uint32_t*>(tiles4);
+    const uint16_t* tiles16 = reinterpret_cast<const uint16_t*>(tiles4);
+
+    // Output addresses: a wave-uniform plane / slab base (scalar registers) plus a 32-bit byte offset per lane (a frame's
+    // planes and its ARGB image stay below 4 GB: at most 16383 x 16383 pixels).
+    const uint32_t ystride = 16u * uint32_t(mbw), cstride = 8u * uint32_t(mbw);
+    uint8_t* const Y = Yp ? Yp + fr.y_off : nullptr;
+    const uint8_t* const A = (Ap != nullptr && fr.has_alpha) ? Ap + fr.alpha_off : nullptr;
+    uint8_t* const dst = out ? out + fr.argb_off : nullptr;
+
+    // ---- luma rows + ARGB: thread = 4 pixels x 2 rows (one chroma sample pair: its rounded terms are computed once),
+    //      half a wavefront = 128 pixels of two rows (512 contiguous bytes of ARGB per row) ----
+    const int q = t & 31, px = c0 + 4 * q;
+    const int k = (4 * q + shift) >> 4, c4 = (4 * q + shift) & 15;         // source tile / column inside it
+    const int rp = t >> 5;                                                 // row pair inside the tile row (shift is even)
+    const int py0 = 16 * ty - shift + 2 * rp;
+    if (k < nt && px < int(ystride) && py0 >= 0 && py0 < 16 * mbh) {
+        const int npx = min(4, width - px);
+        const uint32_t lbase = uint32_t(k) * uint32_t(kTileBytes / 4) + uint32_t(c4 >> 2);        // dword index of the tile row's first luma dword for this lane
+        {
+            const uint32_t ya = tiles32[lbase + 8 * rp];
+            const uint32_t yb = tiles32[lbase + 8 * rp + 4];
+            if (Y) {
+                const uint32_t yo = uint32_t(py0) * ystride + uint32_t(px);
+                WP_NT_STORE(reinterpret_cast<uint32_t*>(Y + size_t(yo)), ya);
+                WP_NT_STORE(reinterpret_cast<uint32_t*>(Y + size_t(yo + ystride)), yb);
+            }
+            if (dst && py0 < height && px < width) {
+                const uint32_t ci = 2u * lbase + 4u * uint32_t(rp) - uint32_t(c4 >> 2);   // 16-bit index of the two chroma samples: k * 192 + 4 * rp + (c4 >> 2)
+                const uint32_t u2 = tiles16[ci + kTileCb / 2], v2 = tiles16[ci + kTileCr / 2];
+                const ChromaTerms t0 = chroma_terms(int(u2 & 0xff), int(v2 & 0xff));
+                const ChromaTerms t1 = chroma_terms(int(u2 >> 8), int(v2 >> 8));
+                const bool any_tie = __builtin_amdgcn_ballot_w64(t0.tie || t1.tie) != 0;
+                const uint32_t pix0 = uint32_t(py0) * uint32_t(width) + uint32_t(px);
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int py = py0 + rr;
+                    if (py >= height) break;
+                    const uint32_t pix = pix0 + (rr ? uint32_t(width) : 0u);
+                    uint32_t a4 = 0xffffffffu;
+                    if (A) {
+                        a4 = 0;
+                        for (int j = 0; j < npx; ++j) a4 |= uint32_t(A[size_t(pix + uint32_t(j))]) << (8 * j);
+                    }
+                    const uint4 o = convert_row4(rr ? yb : ya, t0, t1, a4, any_tie);
+                    uint8_t* p = dst + size_t(pix * 4u);
+                    if (npx == 4 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                        const u32x4 ov4 = {o.x, o.y, o.z, o.w};
+                        WP_NT_STORE(reinterpret_cast<u32x4*>(p), ov4);
+                    } else {
+                        const uint32_t ov[4] = {o.x, o.y, o.z, o.w};
+                        for (int j = 0; j < npx; ++j) reinterpret_cast<uint32_t*>(p)[j] = ov[j];
+                    }
+                }
+            }
+        }
+    }
+    // ---- chroma rows: 2 planes x 8 rows x (8 tiles x 2 dwords) ----
+    if (Up && Vp) {
+        {
+            const int plane = t >> 7, row = (t >> 4) & 7, dw = t & 15;
+            const int cy = 8 * ty - (shift >> 1) + row, cx = (c0 >> 1) + 4 * dw;
+            const int kk = (4 * dw + (shift >> 1)) >> 3, half = ((4 * dw + (shift >> 1)) >> 2) & 1;
+            if (kk < nt && cy >= 0 && cy < 8 * mbh && cx < int(cstride)) {
+                uint8_t* P = plane ? Vp + fr.v_off : Up + fr.u_off;
+                WP_NT_STORE(reinterpret_cast<uint32_t*>(P + size_t(uint32_t(cy) * cstride + uint32_t(cx))), tiles32[kk * (kTileBytes / 4) + (kTileCb / 4) + 16 * plane + 2 * row + half]);
+            }
+        }
+    }
+}
+
+}  // namespace wpk

@@ -32,13 +32,13 @@ constexpr int kEdgeBytes = 32;      // per MB of a band's last row: 16 Y + 8 Cb 
 struct alignas(16) MbFilterTile {
     uint8_t y[20][48];          // rows 0..3: the 4 rows above, 4..19: own MB rows; cols: abs_col & 31 = MB slot (x & 1) * 16 + col; pitch 48 = 12 dwords (see FilterTile)
     uint8_t c[2][12][16];       // rows 0..3 above, 4..11 own; cols: abs_col & 15 = slot (x & 1) * 8 + col
-    uint8_t pad[16];
 };
 struct alignas(16) MbGroupLds {                          // everything one group (one MB row of the band) keeps in LDS: one base address per lane
     ReconTile rt;
     uint32_t rring[4][8];                                // rring[col & 3]: unfiltered bottom row of the MB above: Y (4 dwords), U (2), V (2)
     MbFilterTile ft;
-};                                                       // 960 + 128 + 1360 = 2448 B = 612 dwords: groups start 4 banks apart
+};                                                       // 960 + 128 + 1344 = 2432 B = 608 dwords: 9728 B per wavefront, 77.9 KB per workgroup:
+                                                         // two workgroups leave a CU 8 KB of LDS, enough for a finishing-pass workgroup beside them
 struct alignas(16) MbWaveLds {
     MbGroupLds grp[kBandRows];
 };

@@ -19,11 +19,15 @@ namespace wpk {
 // rounded chroma contributions of one (Cb, Cr) sample, shared by the 2x2 luma samples it covers
 struct ChromaTerms { int r, g, b; bool tie; };
 __device__ __forceinline__ ChromaTerms chroma_terms(int cbv, int crv) {
+    // Each term is floor(rational + 1/2) of an integer in -128..127 (two of them for G).  The multiply-and-shift forms below
+    // give exactly those floors for every argument (tools/convert_constants.py searches the constants and checks all 256 /
+    // 65536 arguments against the exact rational); they need no division (v_mul_hi_u32 runs at a quarter of the rate of the
+    // 24-bit multiplies used here, and the finishing pass is bound by instruction issue when it overlaps reconstruction).
     const int cb = cbv - 128, cr = crv - 128;
     ChromaTerms t;
-    t.r = (5743 * cr + 2048) >> 12;                                                        // floor(1.402 cr + 0.5)
-    t.b = int(uint32_t(1772 * cb + 500 + 1000000) / 1000u) - 1000;                         // floor(1.772 cb + 0.5)
-    t.g = int(uint32_t(500000 - 344136 * cb - 714136 * cr + 200000000) / 1000000u) - 200;  // floor(0.5 - 0.344136 cb - 0.714136 cr)
+    t.r = (__mul24(5743, cr) + 2048) >> 12;                                  // floor(1.402 cr + 0.5)
+    t.b = (__mul24(3629, cb) + 1031) >> 11;                                  // floor(1.772 cb + 0.5)
+    t.g = (1048616 - __mul24(721705, cb) - __mul24(1497652, cr)) >> 21;      // floor(0.5 - 0.344136 cb - 0.714136 cr)
     t.tie = cb == -50 && cr == 50;
     return t;
 }

@@ -49,9 +49,16 @@ class DeviceLossyBatch:
 
     def second_workspace(self):
         """A second workspace of the same size (LossyPipeline alternates between the two)."""
-        if getattr(self, "work2", None) is None:
-            self.work2 = torch.empty(max(self.work_bytes, 256), dtype=torch.uint8, device=self.device)
-        return self.work2
+        return self.workspace(1)
+
+    def workspace(self, k):
+        """Workspace number k (0 = the batch's own); further ones are allocated on first use (LossyPipeline rotates them)."""
+        if k == 0:
+            return self.work
+        extra = self.__dict__.setdefault("_extra_work", {})
+        if k not in extra:
+            extra[k] = torch.empty(max(self.work_bytes, 256), dtype=torch.uint8, device=self.device)
+        return extra[k]
 
     def recon(self, planes=True, work=None):
         """Reconstruction into the tiled workspace; planes=True also writes the unfiltered row-major planes."""
@@ -123,12 +130,13 @@ class LossyPipeline:
     hang once many streams existed in the process (a queue whose barrier packet waits for the other stream's kernel can
     starve that stream when the two share a hardware pipe).  At most `max_in_flight` steps are queued ahead of the GPU."""
 
-    def __init__(self, device="cuda:0", max_in_flight=3, split=0.6, finish_delay_us=40, one_launch=False):
+    def __init__(self, device="cuda:0", max_in_flight=3, split=0.6, finish_delay_us=40, one_launch=False, workspaces=2):
         self.device = torch.device(device)
         self.s_main = torch.cuda.Stream(self.device)
         self.s_finish = torch.cuda.Stream(self.device)
         self.max_in_flight = max_in_flight
         self.split = split
+        self.workspaces = max(2, workspaces)
         self.one_launch = one_launch    # reconstruction + loop filter as one launch (wp_vp8_recon_filter_dev), the whole finishing pass of the step before beside it
         self.finish_delay_cycles = int(finish_delay_us * 2100)     # torch.cuda._sleep counts clock cycles (~2.1 GHz under load)
         self._queued = []               # events of the steps not yet known to be complete, oldest first
@@ -165,14 +173,16 @@ class LossyPipeline:
         timing events of THIS step once its finishing pass has been enqueued (by the next submit() or drain())."""
         while len(self._queued) >= self.max_in_flight:
             self._queued.pop(0).synchronize()
-        work = db.work if (self._k & 1) == 0 else db.second_workspace()
+        work = db.workspace(self._k % self.workspaces)
         self._k += 1
         prev = self._pending
         marks = {}
         if self.one_launch:
             with torch.cuda.stream(self.s_main):
-                if self._phase2_done is not None:
-                    self.s_main.wait_event(self._phase2_done)       # the finishing pass before the one that runs beside this launch
+                # the finishing pass that last read the workspace this launch is about to overwrite
+                hist = self.__dict__.setdefault("_finish_hist", [])
+                if len(hist) >= self.workspaces - 1:
+                    self.s_main.wait_event(hist[-(self.workspaces - 1)])
                 marks["r0"] = self._mark(self.s_main, timing)
                 db.recon_filter(work=work)
                 marks["r1"] = self._mark(self.s_main, timing)
@@ -189,6 +199,8 @@ class LossyPipeline:
                     pmarks["c1"] = self._mark(self.s_finish, ptiming)
                     done_prev = self._event(self.s_finish)
                 self._phase2_done = done_prev
+                self._finish_hist.append(done_prev)
+                del self._finish_hist[:-4]
                 self._queued.append(done_prev)
                 if ptiming is not None:
                     ptiming.append(pmarks)
