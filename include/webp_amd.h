@@ -130,6 +130,11 @@ int wp_debug_set_frames_per_launch(int frames);
  * wp_vp8_plan fills stile_base in the (host) descriptors and returns the workspace size for the batch;
  * call it before copying the descriptors to the device.  The workspace must be 256-byte aligned. */
 int wp_vp8_plan(int n, wp_vp8_frame* frames, uint64_t* work_bytes);
+/* Per-item validity of a descriptor array (no counterpart in the reference, which decodes one image per call: there "a bad
+ * image fails alone" is automatic).  status[i] = WP_OK or WP_ERR_INVALID; returns the number of bad items.  The batched
+ * entry points refuse a batch that contains a bad descriptor before anything is launched; a caller that wants the good
+ * items decoded drops the bad ones first. */
+int wp_vp8_check_frames(int n, const wp_vp8_frame* frames, int* status);
 
 /* Intra prediction + inverse WHT/DCT for n frames.
  * Replaces prepareYBR / inverseWHT16 / inverseDCT4* / reconstructMacroblock / copy
@@ -235,6 +240,13 @@ int wp_vp8_decode_to_argb(int n, const wp_vp8_frame* frames,
                           const int16_t* coeff, size_t n_coeff_blocks,
                           uint8_t* out_y, uint8_t* out_u, uint8_t* out_v,
                           const uint8_t* alpha, uint8_t* out_argb);
+/* The two halves on their own.  wp_vp8_recon: intra prediction + inverse WHT/DCT only -- the
+ * UNFILTERED planes, i.e. Y/Cb/Cr as Vp8Decoder.decodeFrame holds them before simpleFilter / normalFilter run
+ * (Vp8Decoder.hx:345-354).  wp_vp8_loopfilter: simpleFilter / normalFilter (Vp8Decoder.hx:417-486) in place on row-major,
+ * MB-padded planes; filt holds one record per MB, indexed by mb_base like the MB records. */
+int wp_vp8_recon(int n, const wp_vp8_frame* frames, const uint32_t* mb, size_t n_mb, const int16_t* coeff, size_t n_coeff_blocks,
+                 uint8_t* out_y, uint8_t* out_u, uint8_t* out_v);
+int wp_vp8_loopfilter(int n, const wp_vp8_frame* frames, const uint32_t* filt, size_t n_mb, uint8_t* y, uint8_t* u, uint8_t* v);
 int wp_yuv420_to_argb(int n, const wp_vp8_frame* frames, const uint8_t* y, const uint8_t* u, const uint8_t* v,
                       const uint8_t* alpha, uint8_t* out_argb);
 int wp_vp8l_inverse(int n, const wp_vp8l_frame* frames, const uint8_t* pix, size_t pix_len,

@@ -241,3 +241,33 @@ def test_parse_job_delivers_files_in_order_while_parsing():
         job.take(2)
     with ParseJob([], 2) as job:
         assert job.take(5) == []
+
+
+def test_header_is_plain_c99():
+    """include/webp_amd.h compiles as C99 with -pedantic (what a HashLink .hdll shim or any other C binding includes)."""
+    import subprocess, tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".c") as f:
+        f.write('#include "webp_amd.h"\nint main(void) { return (int)sizeof(wp_vp8_frame) - 80; }\n')
+        f.flush()
+        subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), f.name])
+
+
+def test_check_frames_reports_bad_items_alone():
+    """wp_vp8_check_frames: a bad descriptor is reported by index, the others stay usable (a bad image fails alone)."""
+    from webp_amd._lib import Vp8Frame, lib
+    desc = (Vp8Frame * 4)()
+    for i, d in enumerate(desc):
+        d.width, d.height, d.mbw, d.mbh, d.filter_type = 30, 20, 2, 2, i % 3
+    desc[2].width = 33                      # wider than its macroblock grid
+    status = (ctypes.c_int * 4)()
+    assert lib().wp_vp8_check_frames(4, desc, status) == 1
+    assert list(status) == [0, 0, -1, 0]
+
+
+def test_parse_many_lets_a_bad_file_fail_alone():
+    from webp_amd import parse_many, ParsedFile, WebPError
+    datas = [golden_input("1"), b"RIFF\x04\x00\x00\x00WEBP", golden_input("1ll"), golden_input("1")[:300]]
+    got = parse_many(datas, threads=2, strict=False)
+    assert isinstance(got[0], ParsedFile) and isinstance(got[2], ParsedFile)
+    assert isinstance(got[1], WebPError) and "no VP8/VP8L chunk found" in str(got[1])
+    assert isinstance(got[3], WebPError)

@@ -33,6 +33,20 @@ def test_toargb_passthrough_and_types():
     assert isinstance(lo.data, Yuv420) and lo.data.ystride == 16 * 35 and lo.data.uvstride == 8 * 35
     out = Tools.toArgb(lo)
     assert isinstance(out.data, Argb) and out.data.stride == 4 * 550 and out.header.width == 550
+    # the lossy still carries the VP8 frame header (WebPDecoder.hx:236-241; Vp8Decoder.hx:126-184), copied by toArgb (Tools.hx:41-44)
+    h = lo.header
+    assert (h.keyFrame, h.showFrame, h.width, h.height, h.xScale, h.yScale) == (True, True, 550, 368, 0, 0)
+    assert h.firstPartitionLen > 0 and h.versionNumber in (0, 1, 2, 3) and vars(out.header) == vars(h)
+
+
+def test_decode_many_bad_file_fails_alone():
+    """One device batch for a list of files; the file that does not parse holds the reference's error, the rest decode."""
+    from webp_amd import decode_many, Tools, WebPError
+    datas = [golden_input("1"), b"RIFX\x00\x00\x00\x00WEBP", golden_input("2ll"), golden_input("2")]
+    got = decode_many(datas, threads=2)
+    assert isinstance(got[1], WebPError) and "Missing RIFF chunk header" in str(got[1])
+    for i, name in ((0, "1"), (2, "2ll"), (3, "2")):
+        assert np.array_equal(Tools.framesToArgb(got[i])[0], golden_expected(name)[0].reshape(-1)), name
 
 
 @pytest.mark.parametrize("name", ["a", "1x"])
@@ -123,12 +137,14 @@ def test_streaming_decode_equals_per_file_decode():
     argb, items, y, u, v = LossyStream(threads=4, chunk=5).decode(datas)
     torch.cuda.synchronize()
     assert len(items) == len(datas)
+    from oracle import oracle
     for i in (0, 1, 2, 4, 5, 6, len(datas) // 2, len(datas) - 1):
-        img = WebPDecoder.decode(datas[i])
+        want = oracle.decode(datas[i])                      # the CPU restatement of the reference, not another HIP path
         it = items[i]
-        yy, uu, vv = img.data.y, img.data.u, img.data.v
-        assert np.array_equal(y[it["y_off"]:it["y_off"] + yy.size].numpy(), np.asarray(yy).reshape(-1)), paths[i % len(paths)]
-        assert np.array_equal(u[it["u_off"]:it["u_off"] + uu.size].numpy(), np.asarray(uu).reshape(-1))
-        assert np.array_equal(v[it["v_off"]:it["v_off"] + vv.size].numpy(), np.asarray(vv).reshape(-1))
-        want = np.asarray(Tools.toArgb(img).data.pix).reshape(-1)
-        assert np.array_equal(argb[it["argb_off"]:it["argb_off"] + want.size].numpy(), want), paths[i % len(paths)]
+        for name, slab in (("y", y), ("u", u), ("v", v)):
+            w = want[name]
+            assert np.array_equal(slab[it[name + "_off"]:it[name + "_off"] + w.size].numpy(), w), (paths[i % len(paths)], name)
+        w = want["to_argb"]
+        assert np.array_equal(argb[it["argb_off"]:it["argb_off"] + w.size].numpy(), w), paths[i % len(paths)]
+    with pytest.raises(ValueError, match="ALPH"):           # stills with alpha are refused, not decoded without their alpha
+        LossyStream(threads=2, chunk=2).decode([open(os.path.join(ROOT, "tests", "golden", "inputs", "a.webp"), "rb").read()])

@@ -256,3 +256,45 @@ def test_inconsistent_transform_lists_are_refused():
     vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     with pytest.raises(WebPError, match="bad wp_vp8l_frame"):
         check(lib().wp_vp8l_inverse(1, desc, vp(buf), buf.size, vp(buf), 16, vp(buf.copy()), buf.size, 0))
+
+
+@pytest.mark.parametrize("shape", [(32769, 130), (40001, 70)])
+def test_alpha_unfilter_planes_wider_than_32767(shape):
+    """A raw ALPH plane takes its size from the 24-bit VP8X canvas (WebPDecoder.hx:133-148): widths beyond 15 bits, rows not
+    dword-aligned (the one-pixel-skew row wavefront), more than one 64-row band."""
+    from oracle import oracle
+    from webp_amd._lib import AlphaFrame, lib, check
+    w, h = shape
+    rng = np.random.default_rng(w)
+    for f in (1, 3):
+        a = rng.integers(0, 256, w * h, dtype=np.uint8)
+        if f == 3:
+            a = (a // 8).astype(np.uint8)
+        desc = (AlphaFrame * 1)()
+        desc[0].width, desc[0].height, desc[0].filter = w, h, f
+        out = np.zeros(w * h, np.uint8)
+        vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+        check(lib().wp_alpha_unfilter(1, desc, vp(a), a.size, vp(out), out.size))
+        assert np.array_equal(out, oracle.unfilter_alpha(a, w, f)), (w, h, f)
+
+
+def test_host_pointer_halves_recon_and_loopfilter():
+    """wp_vp8_recon (unfiltered planes) and wp_vp8_loopfilter (in place on row-major planes), SURVEY 8b items 2-3."""
+    from oracle import oracle
+    from packed_util import random_batch
+    from webp_amd._lib import check, lib
+    rb = random_batch(12, 99, max_w=7, max_h=9)
+    y = np.zeros(rb.y_bytes, np.uint8); u = np.zeros(rb.u_bytes, np.uint8); v = np.zeros(rb.v_bytes, np.uint8)
+    vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    check(lib().wp_vp8_recon(rb.n, rb.desc, vp(rb.mb), rb.n_mb, vp(rb.coeff), rb.n_coeff_blocks, vp(y), vp(u), vp(v)))
+    exp = [rb.expected(i) for i in range(rb.n)]
+    for i, e in enumerate(exp):
+        d = rb.desc[i]
+        nmb = d.mbw * d.mbh
+        assert np.array_equal(y[d.y_off:d.y_off + 256 * nmb], e["y0"]) and np.array_equal(u[d.u_off:d.u_off + 64 * nmb], e["u0"])
+    check(lib().wp_vp8_loopfilter(rb.n, rb.desc, vp(rb.filt), rb.n_mb, vp(y), vp(u), vp(v)))
+    for i, e in enumerate(exp):
+        d = rb.desc[i]
+        nmb = d.mbw * d.mbh
+        assert np.array_equal(y[d.y_off:d.y_off + 256 * nmb], e["y"]), i
+        assert np.array_equal(u[d.u_off:d.u_off + 64 * nmb], e["u"]) and np.array_equal(v[d.v_off:d.v_off + 64 * nmb], e["v"]), i

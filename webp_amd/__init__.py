@@ -4,4 +4,4 @@ Host side mirrors the reference's public surface (WebPDecoder.decode / Tools.toA
 pixel work runs in hand-written HIP kernels behind the C ABI declared in include/webp_amd.h."""
 from ._lib import WebPError, lib, SO_PATH  # noqa: F401
 from .decoder import (Image, ImageData, Yuv420, Argb, Anim, AnimImage, AnimFrameHeader, FrameHeader,  # noqa: F401
-                      WebPDecoder, Tools, parse, parse_many, ParsedFile, decode_batch)
+                      WebPDecoder, Tools, parse, parse_many, ParsedFile, decode_batch, decode_many)

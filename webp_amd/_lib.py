@@ -70,6 +70,7 @@ def lib():
     L.wp_debug_set_frames_per_launch.argtypes = [i32]
     L.wp_last_error.argtypes = [ctypes.c_char_p, i32]
     L.wp_vp8_plan.argtypes = [i32, vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.wp_vp8_check_frames.argtypes = [i32, vp, vp]
     L.wp_vp8_recon_dev.argtypes = [i32, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]
     L.wp_vp8_loopfilter_dev.argtypes = [i32, vp, vp, vp, vp, sz, vp, vp, vp, vp]
     L.wp_vp8_finish_dev.argtypes = [i32, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp]
@@ -82,6 +83,8 @@ def lib():
     L.wp_alpha_unfilter_dev.argtypes = [i32, vp, vp, vp, vp, vp]
     L.wp_vp8_decode_to_argb.argtypes = [i32, vp, vp, sz, vp, vp, sz, vp, vp, vp, vp, vp]
     L.wp_yuv420_to_argb.argtypes = [i32, vp, vp, vp, vp, vp, vp]
+    L.wp_vp8_recon.argtypes = [i32, vp, vp, sz, vp, sz, vp, vp, vp]
+    L.wp_vp8_loopfilter.argtypes = [i32, vp, vp, sz, vp, vp, vp]
     L.wp_vp8l_inverse.argtypes = [i32, vp, vp, sz, vp, sz, vp, sz, i32]
     L.wp_alpha_unfilter.argtypes = [i32, vp, vp, sz, vp, sz]
     L.wp_parse.argtypes = [vp, sz, ctypes.POINTER(vp)]
@@ -98,6 +101,8 @@ def lib():
     L.wp_parsed_frame_info.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_int32)]
     L.wp_parsed_frame_buf.argtypes = [vp, i32, i32, ctypes.POINTER(sz)]
     L.wp_parsed_frame_buf.restype = vp
+    L.wp_parsed_frame_vp8l_meta.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_int32)]
+    L.wp_parsed_frame_vp8_header.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_int32)]
     _lib = L
     return L
 

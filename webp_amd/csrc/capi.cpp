@@ -71,15 +71,19 @@ int static_scratch(void** out) {
     return WP_OK;
 }
 
+// 0: usable, 1: bad geometry, 2: misaligned offsets
+int vp8_frame_defect(const wp_vp8_frame& a) {
+    if (a.mbw <= 0 || a.mbh <= 0 || a.mbw > 1024 || a.mbh > 1024 || a.width <= 0 || a.height <= 0 ||
+        a.width > 16 * a.mbw || a.height > 16 * a.mbh || a.filter_type < 0 || a.filter_type > 2) return 1;
+    if ((a.y_off & 15) || (a.u_off & 7) || (a.v_off & 7) || (a.argb_off & 3)) return 2;
+    return 0;
+}
 int check_vp8_frames(int n, const wp_vp8_frame* f) {
     if (n < 0 || (n > 0 && !f)) return fail(WP_ERR_INVALID, "bad frame array");
     for (int i = 0; i < n; ++i) {
-        const wp_vp8_frame& a = f[i];
-        if (a.mbw <= 0 || a.mbh <= 0 || a.mbw > 1024 || a.mbh > 1024 || a.width <= 0 || a.height <= 0 ||
-            a.width > 16 * a.mbw || a.height > 16 * a.mbh || a.filter_type < 0 || a.filter_type > 2)
-            return fail(WP_ERR_INVALID, "bad wp_vp8_frame at index " + std::to_string(i));
-        if ((a.y_off & 15) || (a.u_off & 7) || (a.v_off & 7) || (a.argb_off & 3))
-            return fail(WP_ERR_INVALID, "misaligned plane offset in wp_vp8_frame " + std::to_string(i));
+        const int d = vp8_frame_defect(f[i]);
+        if (d == 1) return fail(WP_ERR_INVALID, "bad wp_vp8_frame at index " + std::to_string(i));
+        if (d == 2) return fail(WP_ERR_INVALID, "misaligned plane offset in wp_vp8_frame " + std::to_string(i));
     }
     return WP_OK;
 }
@@ -193,6 +197,16 @@ int wp_last_error(char* buf, int cap) {
     if (!buf || cap <= 0) return int(g_error.size());
     std::snprintf(buf, size_t(cap), "%s", g_error.c_str());
     return int(g_error.size());
+}
+
+int wp_vp8_check_frames(int n, const wp_vp8_frame* frames, int* status) {
+    if (n < 0 || (n > 0 && (!frames || !status))) return fail(WP_ERR_INVALID, "bad argument");
+    int bad = 0;
+    for (int i = 0; i < n; ++i) {
+        status[i] = vp8_frame_defect(frames[i]) ? WP_ERR_INVALID : WP_OK;
+        bad += status[i] != WP_OK;
+    }
+    return bad;
 }
 
 int wp_vp8_plan(int n, wp_vp8_frame* frames, uint64_t* work_bytes) {
@@ -374,6 +388,8 @@ int wp_vp8l_inverse_dev(int n, const wp_vp8l_frame* fh, const wp_vp8l_frame* fd,
                 w = (w + (1LL << t.bits) - 1) >> t.bits;
             }
             if (t.data_len < need) return fail(WP_ERR_INVALID, "transform data too short in wp_vp8l_frame " + std::to_string(i));
+            if (need && !d_aux) return fail(WP_ERR_INVALID, "wp_vp8l_frame " + std::to_string(i) + " has transform data but no aux slab was given");
+            if (t.type == 3 && t.bits > 0 && !d_tmp) return fail(WP_ERR_INVALID, "wp_vp8l_frame " + std::to_string(i) + " expands packed pixels but no tmp slab was given");
         }
         if (w != a.coded_width) return fail(WP_ERR_INVALID, "coded_width of wp_vp8l_frame " + std::to_string(i) + " does not follow from its transforms");
     }
@@ -437,20 +453,13 @@ Vp8Extents vp8_extents(int n, const wp_vp8_frame* f) {
 
 }  // namespace
 
-extern "C" {
-
-int wp_vp8_decode_to_argb(int n, const wp_vp8_frame* frames, const uint32_t* mb, size_t n_mb, const uint32_t* filt,
-                          const int16_t* coeff, size_t n_coeff_blocks, uint8_t* out_y, uint8_t* out_u, uint8_t* out_v,
-                          const uint8_t* alpha, uint8_t* out_argb) {
-    int rc = ensure_init(); if (rc) return rc;
-    rc = check_vp8_frames(n, frames); if (rc) return rc;
-    if (n == 0) return WP_OK;
-    if (!mb || !filt) return fail(WP_ERR_INVALID, "null record array");
+namespace {
+// bounds of the record / coefficient arrays against the descriptors and the block indices inside the MB records
+int check_vp8_records(int n, const wp_vp8_frame* frames, const uint32_t* mb, size_t n_mb, const int16_t* coeff, size_t n_coeff_blocks) {
     for (int i = 0; i < n; ++i) {
         if (size_t(frames[i].mb_base) + size_t(frames[i].mbw) * frames[i].mbh > n_mb) return fail(WP_ERR_INVALID, "mb_base out of range");
+        if (!mb) continue;
         if (frames[i].coeff_base > n_coeff_blocks) return fail(WP_ERR_INVALID, "coeff_base out of range");
-        // the kernels follow the block indices in the MB records: check them here, where the records are host memory
-        // (the _dev entry points take device buffers on trust)
         const size_t avail = n_coeff_blocks - size_t(frames[i].coeff_base);
         if (avail && !coeff) return fail(WP_ERR_INVALID, "null coefficient array");
         const uint32_t* rec = mb + size_t(frames[i].mb_base) * WP_MB_WORDS;
@@ -460,6 +469,22 @@ int wp_vp8_decode_to_argb(int n, const wp_vp8_frame* frames, const uint32_t* mb,
                 return fail(WP_ERR_INVALID, "coefficient block index out of range in frame " + std::to_string(i) + ", macroblock " + std::to_string(m));
         }
     }
+    return WP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int wp_vp8_decode_to_argb(int n, const wp_vp8_frame* frames, const uint32_t* mb, size_t n_mb, const uint32_t* filt,
+                          const int16_t* coeff, size_t n_coeff_blocks, uint8_t* out_y, uint8_t* out_u, uint8_t* out_v,
+                          const uint8_t* alpha, uint8_t* out_argb) {
+    int rc = ensure_init(); if (rc) return rc;
+    rc = check_vp8_frames(n, frames); if (rc) return rc;
+    if (n == 0) return WP_OK;
+    if (!mb || !filt) return fail(WP_ERR_INVALID, "null record array");
+    // the kernels follow the block indices in the MB records: check them here, where the records are host memory
+    // (the _dev entry points take device buffers on trust)
+    if ((rc = check_vp8_records(n, frames, mb, n_mb, coeff, n_coeff_blocks))) return rc;
     const Vp8Extents ex = vp8_extents(n, frames);
     std::vector<wp_vp8_frame> planned;                          // the caller's descriptors stay untouched
     try { planned.assign(frames, frames + n); } catch (const std::bad_alloc&) { return fail(WP_ERR_NOMEM, "out of memory"); }
@@ -487,6 +512,56 @@ int wp_vp8_decode_to_argb(int n, const wp_vp8_frame* frames, const uint32_t* mb,
     if (out_u) HIP_TRY(hipMemcpy(out_u, du.p, ex.u, hipMemcpyDeviceToHost));
     if (out_v) HIP_TRY(hipMemcpy(out_v, dv.p, ex.v, hipMemcpyDeviceToHost));
     if (out_argb) HIP_TRY(hipMemcpy(out_argb, dargb.p, ex.argb, hipMemcpyDeviceToHost));
+    return WP_OK;
+}
+
+int wp_vp8_recon(int n, const wp_vp8_frame* frames, const uint32_t* mb, size_t n_mb, const int16_t* coeff, size_t n_coeff_blocks,
+                 uint8_t* out_y, uint8_t* out_u, uint8_t* out_v) {
+    int rc = ensure_init(); if (rc) return rc;
+    rc = check_vp8_frames(n, frames); if (rc) return rc;
+    if (n == 0) return WP_OK;
+    if (!mb || !out_y || !out_u || !out_v) return fail(WP_ERR_INVALID, "null pointer");
+    if ((rc = check_vp8_records(n, frames, mb, n_mb, coeff, n_coeff_blocks))) return rc;
+    const Vp8Extents ex = vp8_extents(n, frames);
+    std::vector<wp_vp8_frame> planned;
+    try { planned.assign(frames, frames + n); } catch (const std::bad_alloc&) { return fail(WP_ERR_NOMEM, "out of memory"); }
+    uint64_t work_bytes = 0;
+    if ((rc = wp_vp8_plan(n, planned.data(), &work_bytes))) return rc;
+    DevBuf dfr, dmb, dco, dy, du, dv, dwork;
+    if ((rc = dfr.upload(planned.data(), sizeof(wp_vp8_frame) * size_t(n))) || (rc = dwork.alloc(size_t(work_bytes))) ||
+        (rc = dmb.upload(mb, n_mb * 16)) || (rc = dco.upload(coeff, n_coeff_blocks * 32)) ||
+        (rc = dy.alloc(ex.y)) || (rc = du.alloc(ex.u)) || (rc = dv.alloc(ex.v))) return rc;
+    rc = wp_vp8_recon_dev(n, planned.data(), dfr.as<wp_vp8_frame>(), dmb.as<uint32_t>(), dco.as<int16_t>(), dwork.p, size_t(work_bytes),
+                          dy.as<uint8_t>(), du.as<uint8_t>(), dv.as<uint8_t>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_y, dy.p, ex.y, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_u, du.p, ex.u, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_v, dv.p, ex.v, hipMemcpyDeviceToHost));
+    return WP_OK;
+}
+
+int wp_vp8_loopfilter(int n, const wp_vp8_frame* frames, const uint32_t* filt, size_t n_mb, uint8_t* y, uint8_t* u, uint8_t* v) {
+    int rc = ensure_init(); if (rc) return rc;
+    rc = check_vp8_frames(n, frames); if (rc) return rc;
+    if (n == 0) return WP_OK;
+    if (!filt || !y || !u || !v) return fail(WP_ERR_INVALID, "null pointer");
+    if ((rc = check_vp8_records(n, frames, nullptr, n_mb, nullptr, 0))) return rc;
+    const Vp8Extents ex = vp8_extents(n, frames);
+    std::vector<wp_vp8_frame> planned;
+    try { planned.assign(frames, frames + n); } catch (const std::bad_alloc&) { return fail(WP_ERR_NOMEM, "out of memory"); }
+    uint64_t work_bytes = 0;
+    if ((rc = wp_vp8_plan(n, planned.data(), &work_bytes))) return rc;
+    DevBuf dfr, dfl, dy, du, dv, dwork;
+    if ((rc = dfr.upload(planned.data(), sizeof(wp_vp8_frame) * size_t(n))) || (rc = dwork.alloc(size_t(work_bytes))) ||
+        (rc = dfl.upload(filt, n_mb * 4)) || (rc = dy.upload(y, ex.y)) || (rc = du.upload(u, ex.u)) || (rc = dv.upload(v, ex.v))) return rc;
+    rc = wp_vp8_loopfilter_dev(n, planned.data(), dfr.as<wp_vp8_frame>(), dfl.as<uint32_t>(), dwork.p, size_t(work_bytes),
+                               dy.as<uint8_t>(), du.as<uint8_t>(), dv.as<uint8_t>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(y, dy.p, ex.y, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(u, du.p, ex.u, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(v, dv.p, ex.v, hipMemcpyDeviceToHost));
     return WP_OK;
 }
 
@@ -518,12 +593,16 @@ int wp_vp8l_inverse(int n, const wp_vp8l_frame* frames, const uint8_t* pix, size
     size_t tmp_len = 0;
     for (int i = 0; i < n; ++i) {
         const wp_vp8l_frame& a = frames[i];
-        if (a.width <= 0 || a.height <= 0 || a.coded_width <= 0) return fail(WP_ERR_INVALID, "bad wp_vp8l_frame");
-        if (size_t(a.pix_off) + size_t(4) * a.coded_width * a.height > pix_len) return fail(WP_ERR_INVALID, "pix slab too small");
-        if (size_t(a.out_off) + size_t(swizzle == WP_SWIZZLE_GREEN ? 1 : 4) * a.width * a.height > out_len)
+        if (a.width <= 0 || a.height <= 0 || a.coded_width <= 0 || a.width > 16384 || a.height > 16384 || a.coded_width > 16384)
+            return fail(WP_ERR_INVALID, "bad wp_vp8l_frame");
+        // offsets come from the caller: extent checks must not wrap (off <= len && extent <= len - off)
+        auto fits = [](uint64_t off, uint64_t extent, uint64_t len) { return off <= len && extent <= len - off; };
+        if (!fits(a.pix_off, uint64_t(4) * a.coded_width * a.height, pix_len)) return fail(WP_ERR_INVALID, "pix slab too small");
+        if (!fits(a.out_off, uint64_t(swizzle == WP_SWIZZLE_GREEN ? 1 : 4) * a.width * a.height, out_len))
             return fail(WP_ERR_INVALID, "out slab too small");
         for (int k = 0; k < a.n_transforms && k < WP_VP8L_MAX_TRANSFORMS; ++k)
-            if (size_t(a.t[k].data_off) + size_t(a.t[k].data_len) > aux_len) return fail(WP_ERR_INVALID, "aux slab too small");
+            if (!fits(a.t[k].data_off, a.t[k].data_len, aux_len)) return fail(WP_ERR_INVALID, "aux slab too small");
+        if (a.tmp_off > (uint64_t(1) << 46)) return fail(WP_ERR_INVALID, "tmp_off out of range");
         tmp_len = std::max(tmp_len, size_t(a.tmp_off) + size_t(4) * a.width * a.height);
     }
     DevBuf dfr, dpix, daux, dtmp, dout;
@@ -545,9 +624,10 @@ int wp_alpha_unfilter(int n, const wp_alpha_frame* frames, const uint8_t* src, s
     for (int i = 0; i < n; ++i) {
         const wp_alpha_frame& a = frames[i];
         if (a.width <= 0 || a.height <= 0) return fail(WP_ERR_INVALID, "bad wp_alpha_frame");
-        const size_t px = size_t(a.width) * a.height;
-        if (size_t(a.src_off) + px * (a.src_is_vp8l_rgba ? 4 : 1) > src_len) return fail(WP_ERR_INVALID, "source slab too small");
-        if (size_t(a.dst_off) + px > alpha_len) return fail(WP_ERR_INVALID, "alpha slab too small");
+        const uint64_t px = uint64_t(a.width) * uint64_t(a.height);
+        auto fits = [](uint64_t off, uint64_t extent, uint64_t len) { return off <= len && extent <= len - off; };
+        if (!fits(a.src_off, px * (a.src_is_vp8l_rgba ? 4 : 1), src_len)) return fail(WP_ERR_INVALID, "source slab too small");
+        if (!fits(a.dst_off, px, alpha_len)) return fail(WP_ERR_INVALID, "alpha slab too small");
     }
     DevBuf dfr, dsrc, dal;
     if ((rc = dfr.upload(frames, sizeof(wp_alpha_frame) * size_t(n)))) return rc;

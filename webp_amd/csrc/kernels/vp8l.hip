@@ -642,9 +642,15 @@ void alpha_hrows_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* alph
 // the last row of the band above from memory, in 64-byte blocks fetched one block ahead, as far as that band has
 // announced it (LDS progress word, workgroup-scope release / acquire).
 constexpr int kAlphaWaves = 4;
+__device__ __forceinline__ void publish64(unsigned long long* word, unsigned long long value) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __global__ __launch_bounds__(kAlphaWaves * 64)
 void alpha_unfilter_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* alpha) {
-    __shared__ uint32_t progress[kAlphaWaves];      // ((band + 1) << 15) | pixels of the band's last row that are in memory
+    // ((band + 1) << 32) | pixels of the band's last row that are in memory.  64 bits: a raw ALPH plane takes its size from
+    // the 24-bit VP8X canvas (WebPDecoder.hx:133-148), so neither the pixel count nor the band number fits a 15 / 17-bit split
+    __shared__ unsigned long long progress[kAlphaWaves];
     const wp_alpha_frame& fr = frames[blockIdx.x];
     const int w = fr.width, h = fr.height, filter = fr.filter;
     if ((filter != 1 && filter != 3) || alpha_fast_horizontal(fr)) return;
@@ -665,12 +671,12 @@ void alpha_unfilter_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* a
         uint32_t avail = 0;
         auto wait_above = [&](uint32_t need) {
             if (avail < need) {
-                const uint32_t target = (uint32_t(band) << 15) | need;        // the band above announces itself as (band - 1) + 1
-                uint32_t v;
+                const unsigned long long target = ((unsigned long long)band << 32) | need;        // the band above announces itself as (band - 1) + 1
+                unsigned long long v;
                 while ((v = __hip_atomic_load(&progress[prev_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
                     __builtin_amdgcn_s_sleep(1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                avail = (v >> 15) == uint32_t(band) ? (v & 0x7fffu) : uint32_t(w);
+                avail = (v >> 32) == (unsigned long long)band ? uint32_t(v) : uint32_t(w);
             }
         };
         uint32_t cur = 0, up_prev = 0, abuf = 0, anext = 0;
@@ -706,10 +712,10 @@ void alpha_unfilter_kernel(const wp_alpha_frame* __restrict__ frames, uint8_t* a
             }
             if (has_below && (s & 63) == 63) {
                 const int done = s - 63 + 1;                                   // pixels the band's last row (lane 63) has stored
-                if (done > 0) publish_progress(&progress[wave], (uint32_t(band + 1) << 15) | uint32_t(min(done, w)));
+                if (done > 0) publish64(&progress[wave], ((unsigned long long)(band + 1) << 32) | uint32_t(min(done, w)));
             }
         }
-        if (has_below) publish_progress(&progress[wave], (uint32_t(band + 1) << 15) | uint32_t(w));
+        if (has_below) publish64(&progress[wave], ((unsigned long long)(band + 1) << 32) | uint32_t(w));
     }
 }
 

@@ -143,8 +143,10 @@ def parse(data: bytes) -> ParsedFile:
     return ParsedFile(data)
 
 
-def parse_many(datas: List[bytes], threads: int = 0) -> List[ParsedFile]:
-    """parse() for a list of files on `threads` native host threads (0 = all hardware threads); raises on the first bad file."""
+def parse_many(datas: List[bytes], threads: int = 0, strict: bool = True) -> List[ParsedFile]:
+    """parse() for a list of files on `threads` native host threads (0 = all hardware threads).  strict: raise on the first
+    bad file (what a loop over WebPDecoder.decode would do); otherwise a bad file fails alone: its slot holds the WebPError
+    the reference would have thrown for it and every other file is parsed."""
     L = lib()
     n = len(datas)
     if n == 0:
@@ -154,9 +156,26 @@ def parse_many(datas: List[bytes], threads: int = 0) -> List[ParsedFile]:
     out = (ctypes.c_void_p * n)()
     status = (ctypes.c_int * n)()
     rc = L.wp_parse_batch(n, ptrs, lens, threads, out, status)
-    files = [ParsedFile(handle=out[i]) for i in range(n) if out[i]]     # owns (and frees) whatever did parse
-    check(rc)
+    files = [ParsedFile(handle=out[i]) if out[i] else None for i in range(n)]     # owns (and frees) whatever did parse
+    if strict:
+        check(rc)
+        return files
+    for i in range(n):
+        if files[i] is None:                 # re-parse the bad one alone to get ITS message (wp_last_error holds the first one's only)
+            try:
+                files[i] = ParsedFile(datas[i])
+            except _lib.WebPError as e:
+                files[i] = e
     return files
+
+
+def decode_many(datas: List[bytes], threads: int = 0):
+    """WebPDecoder.decode for a list of files as ONE device batch; a file that does not parse fails alone: its slot in the
+    returned list holds the WebPError (the String the reference throws), all others their Image."""
+    parsed = parse_many(datas, threads, strict=False)
+    good = [p for p in parsed if isinstance(p, ParsedFile)]
+    images = iter(decode_batch(good)) if good else iter(())
+    return [next(images) if isinstance(p, ParsedFile) else p for p in parsed]
 
 
 class ParseJob:
@@ -322,11 +341,17 @@ def _load_vp8l_meta(f: ParsedFrame):
     f.alpha_transforms = [(int(meta[20 + 3 * k]), int(meta[21 + 3 * k]), int(meta[22 + 3 * k])) for k in range(nat)]
 
 
+def _vp8_header(f: ParsedFrame) -> FrameHeader:
+    """webp.Image.FrameHeader of a lossy frame as Vp8Decoder.decodeFrameHeader fills it (Vp8Decoder.hx:126-184)."""
+    h = (ctypes.c_int32 * 8)()
+    check(lib().wp_parsed_frame_vp8_header(f._owner._h, f._index, h))
+    return FrameHeader(bool(h[0]), int(h[1]), bool(h[2]), int(h[3]), int(h[4]), int(h[5]), int(h[6]), int(h[7]))
+
+
 def decode_batch(files: List[ParsedFile]):
     """Decodes every frame of every parsed file on the current HIP device.  Returns one Image per file,
     with Yuv420 planes (lossy) / Argb pixels (lossless) exactly as WebPDecoder.decode would hold them."""
     L = lib()
-    L.wp_parsed_frame_vp8l_meta.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]
     flat = [(fi, k, fr) for fi, pf in enumerate(files) for k, fr in enumerate(pf.frames)]
     for _, _, fr in flat:
         _load_vp8l_meta(fr)
@@ -406,6 +431,8 @@ def decode_batch(files: List[ParsedFile]):
             frames = [AnimImage(AnimFrameHeader(fr.x, fr.y, fr.width, fr.height, fr.duration, bool(fr.blend), bool(fr.dispose)),
                                 results[(fi, k)]) for k, fr in enumerate(pf.frames)]
             images.append(Image(FrameHeader(width=pf.width, height=pf.height), Anim(frames)))
+        elif pf.kind == 0:           # lossy still: the VP8 frame header (WebPDecoder.hx:236-241 returns lossy.header)
+            images.append(Image(_vp8_header(pf.frames[0]), results[(fi, 0)]))
         else:
             images.append(Image(FrameHeader(width=pf.width, height=pf.height), results[(fi, 0)]))
     return images

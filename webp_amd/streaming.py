@@ -56,7 +56,7 @@ class LossyStream:
     def decode(self, datas: List[bytes]):
         """Returns (argb, items[, y, u, v]): pinned uint8 tensors holding every image's output and, per image, a dict with
         width, height, mbw, mbh and the byte offsets of its outputs.  Raises WebPError on the first file that does not parse
-        or is not a lossy still."""
+        or is not a lossy still without an ALPH chunk (those go through decode_batch, which runs the alpha chain)."""
         n = len(datas)
         chunks = [datas[i:i + self.chunk] for i in range(0, n, self.chunk)]
         job = ParseJob(datas, self.threads, window=3 * self.chunk)     # one work queue; chunks are taken in index order
@@ -88,6 +88,8 @@ class LossyStream:
             for f in files:
                 if f.kind != 0 or not f.frames or f.frames[0].type != 0:
                     raise ValueError("LossyStream handles lossy still images only")
+                if f.frames[0].has_alpha:       # WebPDecoder.decode would put the unfiltered ALPH plane into ImageData.Yuv420.a (WebPDecoder.hx:236-241)
+                    raise ValueError("LossyStream does not decode ALPH planes: use webp_amd.decode_batch for stills with alpha")
                 frames.append(f.frames[0])
             slot = self.slots[k & 1]
             if slot.done is not None:
