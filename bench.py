@@ -112,6 +112,9 @@ def main():
                     "workgroup gives every wavefront the same number of bands and is ~10 %% faster per image)")
     ap.add_argument("--pattern", default="lossy1080_*.webp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the records of the other BASELINE.json configurations (lossless, animation + alpha, 4K, end to end)")
+    ap.add_argument("--total-images", type=int, default=0, help="size of ONE global batch that is sharded over the ranks by webp_amd.sharding (cfg 5: 8192 with --pattern lossy2160_q75_0.webp); "
+                    "0 = every rank decodes --images images (weak scaling, the default)")
     ap.add_argument("--serial", action="store_true", help="one stream per step, no overlap between steps (kernel times as when each runs alone)")
     ap.add_argument("--split", type=float, default=0.6, help="share of a step's frames whose finishing pass runs beside the next reconstruction (the rest: beside the next loop filter)")
     ap.add_argument("--finish-delay-us", type=float, default=40.0, help="how long a finishing pass is held back so that the persistent kernel of its phase is dispatched first")
@@ -140,6 +143,12 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(device))
 
+    shard = None
+    if args.total_images > 0:                        # the global batch's frames all have one size here: equal weights
+        from webp_amd.sharding import shard_by_weight
+        lo, hi = shard_by_weight([1] * args.total_images, rank, world)
+        shard = (lo, hi)
+        args.images = hi - lo
     files, batch, db, paths, t_parse = build_batch(args.images, args.pattern, device)
     n_mb = batch.n_mb
     px_per_step = sum(batch.desc[i].width * batch.desc[i].height for i in range(batch.n))
@@ -180,12 +189,17 @@ def main():
     run(args.steps, marks)
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = [1e3 * elapsed / args.steps]
+    total_px = px_per_step * world
     if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed, -elapsed, float(px_per_step)], device=device, dtype=torch.float64)
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        rank_ms = [1e3 * float(-tmax[1].item()) / args.steps, 1e3 * float(tmax[0].item()) / args.steps]      # fastest, slowest rank
+        elapsed = float(tmax[0].item())
+        total_px = float(tsum[2].item())             # pixels all ranks decoded per step (ranks of a sharded batch can differ by an image)
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * px_per_step * args.steps / elapsed / 1e6
+    value = total_px * args.steps / elapsed / 1e6
 
     # ---- per-kernel launch durations over the timed region (HIP events on each kernel's launch stream) and the roofline
     #      of the dominant kernel.  In the pipelined run a reconstruction shares the GPU with the previous step's
@@ -219,7 +233,7 @@ def main():
             db.decode_to_argb()
         torch.cuda.synchronize()
         serial_ms = 1e3 * (time.perf_counter() - ts0) / args.steps
-    verified = verify_outputs(db, batch, paths, args.images) if rank == 0 else None
+    verified = verify_outputs(db, batch, paths, args.images)          # every rank checks its own outputs (a mismatch ends the job)
     in_bytes = batch.input_bytes()
     yuv_bytes = 384 * n_mb
     argb_bytes = 4 * px_per_step
@@ -264,13 +278,15 @@ def main():
 
     line = {"metric": "decoded Mpix/s (whole node) for batched 1080p lossy WebP", "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32/u8",
+            "higher_is_better": True, "scaling": "strong" if args.total_images > 0 else "weak", "vs_baseline": None, "dtype": "i32/u8",
             "data": "synthetic",
             "config": {"workload": "%d x %dx%d VP8 lossy (%s) per GPU: recon + loop filter + finishing pass (YUV420 planes + ARGB out), inputs resident in HBM"
                                    % (args.images, batch.desc[0].width, batch.desc[0].height,
                                       "libwebp: 8 x q75 m4 normal filter + q90 + q50 sharp3 + simple-filter variant" if args.pattern == "lossy1080_*.webp"
                                       else "bench_data/" + args.pattern),
-                       "images_per_gpu": args.images, "distinct_streams": len(paths), "sharding": "images across ranks, no collective",
+                       "images_per_gpu": args.images, "distinct_streams": len(paths),
+                       "sharding": "images across ranks, no collective" + ("" if shard is None else "; one global batch of %d split by webp_amd.sharding.shard_by_weight, rank 0 holds [%d, %d)" % (args.total_images, shard[0], shard[1])),
+                       "rank_ms_per_step_min_max": [round(v, 4) for v in (rank_ms if len(rank_ms) == 2 else rank_ms * 2)],
                        "macroblocks_per_gpu": n_mb, "coeff_blocks_per_mb": round(batch.n_coeff_blocks / max(n_mb, 1), 3),
                        "host_parse_ms_per_image": round(1e3 * t_parse, 2),
                        "step_pipelining": "none (--serial)" if pipe is None else
@@ -280,6 +296,13 @@ def main():
                        "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 4)},
             "verified_frames": None if verified is None else verified["count"], "verified": verified,
             "roofline": roofline}
+    if rank == 0 and world == 1 and not args.no_secondary:
+        del db, batch, files, pipe
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_secondary
+        line["secondary"] = bench_secondary.run_all(device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(paths)
     if dist is not None:

@@ -52,10 +52,12 @@ class LossyStream:
         self.s_compute = torch.cuda.Stream(self.device)
         self.s_out = torch.cuda.Stream(self.device)
         self.slots = [_Slot(self.device), _Slot(self.device)]
+        self._out_cache = {}            # pinned output slabs of the previous decode(), reused when large enough (allocating ~13 GB of pinned memory costs ~0.4 s)
 
     def decode(self, datas: List[bytes]):
         """Returns (argb, items[, y, u, v]): pinned uint8 tensors holding every image's output and, per image, a dict with
-        width, height, mbw, mbh and the byte offsets of its outputs.  Raises WebPError on the first file that does not parse
+        width, height, mbw, mbh and the byte offsets of its outputs.  The output tensors belong to this object and are reused
+        by its next decode() (copy what must outlive it).  Raises WebPError on the first file that does not parse
         or is not a lossy still without an ALPH chunk (those go through decode_batch, which runs the alpha chain)."""
         n = len(datas)
         chunks = [datas[i:i + self.chunk] for i in range(0, n, self.chunk)]
@@ -66,7 +68,10 @@ class LossyStream:
         def out_slab(name, need):
             t, used = outs.get(name, (None, 0))
             if t is None:                       # sized from the first chunk, with headroom; grows by reallocation if a later chunk needs it
-                t = torch.empty(int(need * len(chunks) * 1.1) + 4096, dtype=torch.uint8, pin_memory=True)
+                want = int(need * len(chunks) * 1.1) + 4096
+                t = self._out_cache.get(name)
+                if t is None or t.numel() < want:
+                    t = torch.empty(want, dtype=torch.uint8, pin_memory=True)
             elif used + need > t.numel():
                 torch.cuda.synchronize(self.device)
                 t2 = torch.empty(int((used + need) * 1.5), dtype=torch.uint8, pin_memory=True)
@@ -137,6 +142,7 @@ class LossyStream:
         for s in self.slots:
             if s.done is not None:
                 s.done.synchronize()
+        self._out_cache = {name: outs[name][0] for name in outs}      # NOTE: the next decode() on this object overwrites what this one returns
         res = [outs["argb"][0] if outs else torch.empty(0, dtype=torch.uint8), items]
         if self.planes:
             res += [outs[p][0] for p in ("y", "u", "v")] if outs else [torch.empty(0, dtype=torch.uint8)] * 3
