@@ -95,6 +95,24 @@ def test_lossy_pipeline_steps(big):
         _check_all(db, rb, "LossyPipeline(one_launch=%s)" % one_launch)
 
 
+def test_many_pipelines_share_two_streams():
+    """Twelve LossyPipeline objects in a row (round 1 created two streams per object and once hung with a high-priority
+    finishing stream after many had been created): all use the same two process-wide streams, and every one decodes right."""
+    from packed_util import random_batch
+    from webp_amd.device import DeviceLossyBatch, LossyPipeline, pipeline_streams
+    rb = random_batch(40, 7, max_w=6, max_h=9)
+    db = DeviceLossyBatch(rb, "cuda:0")
+    s0 = pipeline_streams("cuda:0")
+    for k in range(12):
+        pipe = LossyPipeline("cuda:0", one_launch=bool(k & 1))
+        assert (pipe.s_main, pipe.s_finish) == s0
+        _clear(db)
+        pipe.submit(db); pipe.submit(db)
+        pipe.drain()
+        if k in (0, 11):
+            _check_all(db, rb, "pipeline %d" % k)
+
+
 def test_split_into_several_launches(big):
     """frames_per_launch < n (capi.cpp): the hook caps a launch at 300 frames, so the batch takes four launches per kernel."""
     from webp_amd._lib import check, lib

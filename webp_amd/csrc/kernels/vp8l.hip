@@ -433,6 +433,43 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                     }
                     const int xg = x0 + 4 * g4;
                     const int m = mode_of[g4];
+                    // Fast path: every active lane of the wavefront has the same mode for this 4-pixel group (libwebp picks one
+                    // or two modes for most of an image: the bench streams are select, mode 11, throughout) and no lane is in
+                    // the first row, the first column or the ragged end of its row.  The general code below costs ~54 VALU + 47
+                    // SALU instructions per pixel whatever the modes are; a single known mode without those special cases is a
+                    // dozen.  Modes that read TR (3, 5, 9, 10) stay on the general path (TR of a row's last pixel is special).
+                    {
+                        const int m0 = __builtin_amdgcn_readfirstlane(m);
+                        const bool plain = m == m0 && y > 0 && xg > 0 && xg + 4 <= w;
+                        constexpr uint32_t kNoTR = 0xF9D7u;       // modes 0,1,2,4,6,7,8,11,12,13,14,15
+                        if (__builtin_amdgcn_ballot_w64(!plain) == 0 && ((kNoTR >> m0) & 1u)) {
+                            uint32_t L = Lpx;
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const int j = 4 * g4 + jj;
+                                const uint32_t T = T4[j];
+                                const uint32_t TL = j ? T4[j - 1] : TLfirst;
+                                uint32_t pr;
+                                switch (m0) {
+                                case 0: pr = 0xff000000u; break;
+                                case 1: pr = L; break;
+                                case 2: pr = T; break;
+                                case 4: pr = TL; break;
+                                case 6: pr = avg_px(L, TL); break;
+                                case 7: pr = avg_px(L, T); break;
+                                case 8: pr = avg_px(TL, T); break;
+                                case 11: pr = __builtin_amdgcn_sad_u8(TL, T, 0u) < __builtin_amdgcn_sad_u8(TL, L, 0u) ? L : T; break;
+                                case 12: pr = predict_px(12, L, T, TL, 0u); break;
+                                case 13: pr = predict_px(13, L, T, TL, 0u); break;
+                                default: pr = 0u; break;      // 14, 15: nothing is added
+                                }
+                                L = add_px(in[j], pr);
+                                res[j] = L;
+                            }
+                            Lpx = L;
+                            continue;
+                        }
+                    }
                     const bool m5 = m == 5, m10 = m == 10, is_l = m == 1;
                     const bool use_b = m5 || m10;
                     const bool chain = is_l || use_b || m == 6 || m == 7;

@@ -108,6 +108,21 @@ class DeviceLossyBatch:
         return self.argb[d.argb_off:d.argb_off + 4 * d.width * d.height].cpu().numpy()
 
 
+_PIPELINE_STREAMS = {}
+
+
+def pipeline_streams(device):
+    """The two HIP streams every LossyPipeline of this process uses on `device` (default priority), created once.  A
+    process therefore never holds more than two extra streams per device however many pipelines it builds: HIP multiplexes
+    streams onto GPU_MAX_HW_QUEUES (4) hardware queues, and a stream whose barrier packet waits for a kernel that sits
+    behind it on the same hardware queue can never be released ("the recorded hang")."""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _PIPELINE_STREAMS:
+        _PIPELINE_STREAMS[key] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+    return _PIPELINE_STREAMS[key]
+
+
 class LossyPipeline:
     """Software pipeline over successive device batches, in two phases per step on two HIP streams:
 
@@ -126,14 +141,15 @@ class LossyPipeline:
     `drain()`): `submit()` returns the event of the previous step's outputs (None for the first), `drain()` completes
     everything.
 
-    Both streams have the default priority, on purpose: with a high-priority finishing stream the pipeline was seen to
-    hang once many streams existed in the process (a queue whose barrier packet waits for the other stream's kernel can
-    starve that stream when the two share a hardware pipe).  At most `max_in_flight` steps are queued ahead of the GPU."""
+    one_launch=True (what bench.py uses): reconstruction + loop filter are ONE kernel (wp_vp8_recon_filter_dev) and the whole
+    finishing pass of step k-1 runs beside it.
+
+    Both streams have the default priority and are shared by all pipelines of the process (`pipeline_streams`), on
+    purpose: see DESIGN.md, "the recorded hang".  At most `max_in_flight` steps are queued ahead of the GPU."""
 
     def __init__(self, device="cuda:0", max_in_flight=3, split=0.6, finish_delay_us=40, one_launch=False, workspaces=2):
         self.device = torch.device(device)
-        self.s_main = torch.cuda.Stream(self.device)
-        self.s_finish = torch.cuda.Stream(self.device)
+        self.s_main, self.s_finish = pipeline_streams(self.device)
         self.max_in_flight = max_in_flight
         self.split = split
         self.workspaces = max(2, workspaces)
