@@ -97,6 +97,26 @@ typedef struct wp_vp8l_frame {
     uint64_t tmp_off;           /* byte offset of a 4*width*height scratch area in the tmp slab */
 } wp_vp8l_frame;
 
+/* Token stream of one VP8L image: what decodePix's Huffman reads yield (Vp8LDecoder.hx:254-281, 291-306, 317-319) before
+ * its pixel loop acts on them (:283-290 literal store, :308-316 LZ77 copy, :320-333 colour-cache fill + lookup).  A stream
+ * is a sequence of 32-bit words; the top two bits of a token's first word give its kind, the low 30 its argument:
+ *   WP_TOK_LITERALS  n   followed by n words, one pixel each, bytes R,G,B,A in memory order (what decodePix stores)
+ *   WP_TOK_COPY      len followed by one word: the distance in pixels, already mapped through distanceMap (:50-59)
+ *   WP_TOK_CACHE     key the colour-cache index read from the bitstream
+ * The host emits it (wp_parse_ex with WP_PARSE_VP8L_TOKENS) and checks everything decodePix checks (copy source and end
+ * inside the image, cache index in range): those checks depend on positions only, never on pixel values. */
+#define WP_TOK_LITERALS 0u
+#define WP_TOK_COPY 1u
+#define WP_TOK_CACHE 2u
+typedef struct wp_vp8l_tokens_frame {
+    int32_t coded_width, height; /* size of the decodePix output */
+    int32_t cc_bits;            /* colour-cache bits (Vp8LDecoder.hx:226-234): 0 = no cache, else 1..11 */
+    int32_t reserved;
+    uint64_t tok_off;           /* byte offset of the stream in the token slab (multiple of 4) */
+    uint64_t n_words;           /* its length in 32-bit words */
+    uint64_t pix_off;           /* byte offset of the result (RGBA, 4*coded_width*height) in the pix slab (multiple of 16) */
+} wp_vp8l_tokens_frame;
+
 /* One alpha plane (WebPDecoder.hx:357-411). */
 typedef struct wp_alpha_frame {
     int32_t width, height;      /* alphaStride = width */
@@ -224,6 +244,18 @@ int wp_vp8l_inverse_dev(int n, const wp_vp8l_frame* frames_host, const wp_vp8l_f
                         uint8_t* d_pix, const uint8_t* d_aux, uint8_t* d_tmp, uint8_t* d_out,
                         int swizzle, void* stream);
 
+/* The pixel loop of decodePix on the device (first slice): literal stores, LZ77 copies and the lazily
+ * filled colour cache (Vp8LDecoder.hx:283-290, 308-316, 320-333) for n token streams, one wavefront per image.  Writes at
+ * pix_off exactly the bytes decodePix returns, i.e. what wp_vp8l_inverse_dev consumes as d_pix.  frames_host gives the
+ * launch geometry; the streams themselves are device memory the library cannot inspect: they must come from
+ * wp_parse_ex(WP_PARSE_VP8L_TOKENS) or have passed wp_vp8l_check_tokens.  (The kernel still never reads or writes outside
+ * a frame's stream and pixel extents: it stops at the first token that would.) */
+int wp_vp8l_resolve_dev(int n, const wp_vp8l_tokens_frame* frames_host, const wp_vp8l_tokens_frame* d_frames,
+                        const uint32_t* d_tokens, uint8_t* d_pix, void* stream);
+/* Host-side validity of one stream against its descriptor: WP_OK, or WP_ERR_FORMAT with decodePix's message
+ * ("Invalid LZ77 parameters", "Invalid color cache index", "null color cache") or a note on what is malformed. */
+int wp_vp8l_check_tokens(const wp_vp8l_tokens_frame* frame, const uint32_t* tokens /* the frame's stream, host memory */);
+
 /* Alpha plane: optional green-channel extraction + unfilterAlpha (WebPDecoder.hx:311-411). */
 int wp_alpha_unfilter_dev(int n, const wp_alpha_frame* frames_host, const wp_alpha_frame* d_frames,
                           const uint8_t* d_src, uint8_t* d_alpha, void* stream);
@@ -253,6 +285,9 @@ int wp_vp8l_inverse(int n, const wp_vp8l_frame* frames, const uint8_t* pix, size
                     const uint8_t* aux, size_t aux_len, uint8_t* out, size_t out_len, int swizzle);
 int wp_alpha_unfilter(int n, const wp_alpha_frame* frames, const uint8_t* src, size_t src_len,
                       uint8_t* alpha, size_t alpha_len);
+/* wp_vp8l_resolve_dev on host memory; every stream is checked (wp_vp8l_check_tokens) before anything is uploaded. */
+int wp_vp8l_resolve(int n, const wp_vp8l_tokens_frame* frames, const uint32_t* tokens, size_t n_words,
+                    uint8_t* pix, size_t pix_len);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Host side of the path (C++ mirror of the reference's Haxe host code; the reference toolchain  */
@@ -263,6 +298,11 @@ typedef struct wp_parsed wp_parsed;      /* opaque: result of parsing one .webp 
 /* Mirrors WebPDecoder.decode's container walk (WebPDecoder.hx:179-309) and the parse half of
  * Vp8Decoder / Vp8LDecoder; produces the packed buffers above for every frame in the file. */
 int wp_parse(const uint8_t* data, size_t len, wp_parsed** out);
+/* flags: WP_PARSE_VP8L_TOKENS -- the top-level image of every VP8L still / ANMF frame is left as a token stream
+ * (wp_parsed_frame_buf which = 6, colour-cache bits in wp_parsed_frame_vp8l_meta[3]) instead of being resolved into
+ * pixels on the host (which = 3 is then empty); transform data and VP8L-coded alpha images are resolved as before. */
+#define WP_PARSE_VP8L_TOKENS 1
+int wp_parse_ex(const uint8_t* data, size_t len, int flags, wp_parsed** out);
 void wp_parsed_free(wp_parsed* p);
 /* n independent files on up to n_threads host threads (0 = one per hardware thread).  The reference is single-threaded
  *  but keeps all mutable state in its decoder objects, so one decoder per host thread is what a Haxe caller
@@ -270,6 +310,7 @@ void wp_parsed_free(wp_parsed* p);
  * throughput long before the kernels do).  out[i] receives the parsed object or NULL, status[i] its wp_status;
  * returns 0 if every file parsed, else the first failing status (wp_last_error holds that file's message). */
 int wp_parse_batch(int n, const uint8_t* const* data, const size_t* len, int n_threads, wp_parsed** out, int* status);
+int wp_parse_batch_ex(int n, const uint8_t* const* data, const size_t* len, int n_threads, int flags, wp_parsed** out, int* status);
 /* The same loop as wp_parse_batch, but running in the background so that a caller can consume the files in index order
  * while later ones are still being parsed (one work queue for the whole set: no thread idles while another finishes a
  * large file, whatever the size of the chunks the caller consumes).  At most `window` files beyond the last index waited

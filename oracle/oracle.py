@@ -106,3 +106,14 @@ def inverse_color_indexing(old_width, bits, tpix, pix, h):
     lib().wo_inverse_color_indexing(old_width, bits, _p(tpix), _p(pix), pix.size, _p(dst), h); return dst
 def unfilter_alpha(alpha, stride, filt):
     a = alpha.copy(); lib().wo_unfilter_alpha(_p(a), a.size, stride, filt); return a
+
+def resolve_tokens(w, h, cc_bits, tokens):
+    """decodePix's pixel loop (Vp8LDecoder.hx:254-333) over a token stream: the RGBA bytes decodePix returns."""
+    tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
+    pix = np.zeros(4 * w * h, np.uint8)
+    L = lib()
+    L.wo_resolve_tokens.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p]
+    rc = L.wo_resolve_tokens(w, h, cc_bits, _p(tokens), tokens.size, _p(pix))
+    if rc:
+        raise OracleError(L.wo_last_error().decode())
+    return pix

@@ -1315,6 +1315,47 @@ done:
     return rc;
 }
 
+/* The pixel loop of decodePix (Vp8LDecoder.hx:254-333) driven by a token stream (include/webp_amd.h, wp_vp8l_tokens_frame)
+ * instead of by Huffman reads: the checker for wp_vp8l_resolve[_dev].  Literal store :283-290, LZ77 copy :308-316 (a forward
+ * byte copy), colour-cache fill up to the current pixel and lookup :320-333.  Returns 0, or the error decodePix would raise. */
+int wo_resolve_tokens(int w, int h, int ccBits, const uint32_t* tok, long long nWords, uint8_t* pix) {
+    long long plen = 4LL * w * h, p = 0, cachedP = 0, pos = 0;
+    int ccLen = ccBits ? 1 << ccBits : 0, ccShift = 32 - ccBits, rc = 0;
+    uint32_t* ccEntries = ccLen ? (uint32_t*)calloc(ccLen, sizeof(uint32_t)) : NULL;
+    while (pos < nWords) {
+        uint32_t kind = tok[pos] >> 30, arg = tok[pos] & 0x3fffffffu;
+        if (kind == 0) {
+            if (arg > nWords - pos - 1 || 4LL * arg > plen - p) { rc = fail(WO_ERR_FORMAT, "token stream: literal run out of range"); break; }
+            for (uint32_t i = 0; i < arg; i++) {
+                uint32_t v = tok[pos + 1 + i];
+                pix[p++] = (uint8_t)v; pix[p++] = (uint8_t)(v >> 8); pix[p++] = (uint8_t)(v >> 16); pix[p++] = (uint8_t)(v >> 24);
+            }
+            pos += 1 + (long long)arg;
+        } else if (kind == 1) {
+            if (nWords - pos < 2) { rc = fail(WO_ERR_FORMAT, "token stream: copy without a distance"); break; }
+            long long dist = tok[pos + 1], pEnd = p + 4LL * arg, q = p - 4 * dist;
+            if (dist == 0 || q < 0 || pEnd > plen) { rc = fail(WO_ERR_FORMAT, "Invalid LZ77 parameters"); break; }
+            while (p < pEnd) pix[p++] = pix[q++];
+            pos += 2;
+        } else if (kind == 2) {
+            if (!ccEntries) { rc = fail(WO_ERR_NULL, "null color cache"); break; }
+            if (p >= plen) { rc = fail(WO_ERR_FORMAT, "token stream: too many pixels"); break; }
+            while (cachedP < p) {
+                uint32_t argb = ((uint32_t)pix[cachedP] << 16) | ((uint32_t)pix[cachedP + 1] << 8) | pix[cachedP + 2] | ((uint32_t)pix[cachedP + 3] << 24);
+                ccEntries[(argb * 0x1e35a7bdu) >> ccShift] = argb;
+                cachedP += 4;
+            }
+            if ((int)arg >= ccLen) { rc = fail(WO_ERR_FORMAT, "Invalid color cache index"); break; }
+            uint32_t argb = ccEntries[arg];
+            pix[p++] = (argb >> 16) & 0xFF; pix[p++] = (argb >> 8) & 0xFF; pix[p++] = argb & 0xFF; pix[p++] = (argb >> 24) & 0xFF;
+            pos += 1;
+        } else { rc = fail(WO_ERR_FORMAT, "token stream: unknown token kind"); break; }
+    }
+    if (!rc && p != plen) rc = fail(WO_ERR_FORMAT, "token stream: fewer pixels than the image holds");
+    free(ccEntries);
+    return rc;
+}
+
 /* Vp8LDecoder.hx:78-122 */
 static int decodeTransform(L* d, int* w, int h, Transform* t) {
     t->oldWidth = *w;

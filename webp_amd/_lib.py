@@ -34,6 +34,11 @@ class AlphaFrame(ctypes.Structure):        # wp_alpha_frame
                 ("src_is_vp8l_rgba", ctypes.c_int32), ("src_off", ctypes.c_uint64), ("dst_off", ctypes.c_uint64)]
 
 
+class Vp8lTokensFrame(ctypes.Structure):   # wp_vp8l_tokens_frame
+    _fields_ = [("coded_width", ctypes.c_int32), ("height", ctypes.c_int32), ("cc_bits", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("tok_off", ctypes.c_uint64), ("n_words", ctypes.c_uint64), ("pix_off", ctypes.c_uint64)]
+
+
 class Vp8BatchSizes(ctypes.Structure):   # wp_vp8_batch_sizes
     _fields_ = [(k, ctypes.c_uint64) for k in ("n_mb", "n_coeff_blocks", "y_bytes", "u_bytes", "v_bytes", "argb_bytes",
                                                "alpha_bytes", "work_bytes")]
@@ -87,7 +92,12 @@ def lib():
     L.wp_vp8_loopfilter.argtypes = [i32, vp, vp, sz, vp, vp, vp]
     L.wp_vp8l_inverse.argtypes = [i32, vp, vp, sz, vp, sz, vp, sz, i32]
     L.wp_alpha_unfilter.argtypes = [i32, vp, vp, sz, vp, sz]
+    L.wp_vp8l_resolve_dev.argtypes = [i32, vp, vp, vp, vp, vp]
+    L.wp_vp8l_check_tokens.argtypes = [vp, vp]
+    L.wp_vp8l_resolve.argtypes = [i32, vp, vp, sz, vp, sz]
     L.wp_parse.argtypes = [vp, sz, ctypes.POINTER(vp)]
+    L.wp_parse_ex.argtypes = [vp, sz, i32, ctypes.POINTER(vp)]
+    L.wp_parse_batch_ex.argtypes = [i32, vp, vp, i32, i32, vp, vp]
     L.wp_parsed_free.argtypes = [vp]
     L.wp_parse_batch.argtypes = [i32, vp, vp, i32, vp, vp]
     L.wp_parsed_free.restype = None

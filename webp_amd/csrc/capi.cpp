@@ -29,6 +29,7 @@ int wpk_launch_yuv420_to_argb(int n, int grid_x, const wp_vp8_frame* d_frames, c
                               const uint8_t* d_v, const uint8_t* d_alpha, uint8_t* d_argb, hipStream_t stream);
 int wpk_launch_vp8l(int n, const wp_vp8l_frame* frames_host, const wp_vp8l_frame* d_frames, uint8_t* d_pix, const uint8_t* d_aux,
                     uint8_t* d_tmp, uint8_t* d_out, int swizzle, hipStream_t stream);
+int wpk_launch_vp8l_resolve(int n, const wp_vp8l_tokens_frame* d_frames, const uint32_t* d_tokens, uint8_t* d_pix, hipStream_t stream);
 int wpk_launch_alpha(int n, const wp_alpha_frame* frames_host, const wp_alpha_frame* d_frames, const uint8_t* d_src, uint8_t* d_alpha,
                      hipStream_t stream);
 }
@@ -399,6 +400,53 @@ int wp_vp8l_inverse_dev(int n, const wp_vp8l_frame* fh, const wp_vp8l_frame* fd,
     return WP_OK;
 }
 
+static int bad_tokens_frame(const wp_vp8l_tokens_frame& a) {
+    return a.coded_width <= 0 || a.height <= 0 || a.coded_width > 16384 || a.height > 16384 || a.cc_bits < 0 || a.cc_bits > 11 ||
+           (a.tok_off & 3) || (a.pix_off & 15) || a.n_words >= (uint64_t(1) << 32) - 256;
+}
+
+int wp_vp8l_resolve_dev(int n, const wp_vp8l_tokens_frame* fh, const wp_vp8l_tokens_frame* fd, const uint32_t* d_tokens, uint8_t* d_pix, void* stream) {
+    int rc = ensure_init(); if (rc) return rc;
+    if (n < 0 || (n > 0 && (!fh || !fd || !d_tokens || !d_pix))) return fail(WP_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i)
+        if (bad_tokens_frame(fh[i])) return fail(WP_ERR_INVALID, "bad wp_vp8l_tokens_frame at index " + std::to_string(i));
+    if (n == 0) return WP_OK;
+    const int e = wpk_launch_vp8l_resolve(n, fd, d_tokens, d_pix, hipStream_t(stream));
+    if (e) return hip_fail(hipError_t(e), "vp8l resolve launch");
+    return WP_OK;
+}
+
+// The walk of the kernel without the pixels: positions and indices only (what decodePix checks, Vp8LDecoder.hx:283-289, 308-316).
+int wp_vp8l_check_tokens(const wp_vp8l_tokens_frame* frame, const uint32_t* tok) {
+    if (!frame || (!tok && frame->n_words)) return fail(WP_ERR_INVALID, "bad argument");
+    if (bad_tokens_frame(*frame)) return fail(WP_ERR_INVALID, "bad wp_vp8l_tokens_frame");
+    const uint64_t total = uint64_t(frame->coded_width) * uint64_t(frame->height), n = frame->n_words;
+    const uint32_t cc_size = frame->cc_bits ? 1u << frame->cc_bits : 0u;
+    uint64_t pos = 0, p = 0;
+    while (pos < n) {
+        const uint32_t kind = tok[pos] >> 30, arg = tok[pos] & 0x3fffffffu;
+        if (kind == WP_TOK_LITERALS) {
+            if (arg > n - pos - 1) return fail(WP_ERR_FORMAT, "token stream: literal run past the end of the stream");
+            if (arg > total - p) return fail(WP_ERR_FORMAT, "token stream: more pixels than the image holds");
+            pos += 1 + uint64_t(arg); p += arg;
+        } else if (kind == WP_TOK_COPY) {
+            if (n - pos < 2) return fail(WP_ERR_FORMAT, "token stream: copy without a distance");
+            const uint32_t dist = tok[pos + 1];
+            if (dist == 0 || dist > p || arg > total - p) return fail(WP_ERR_FORMAT, "Invalid LZ77 parameters");
+            pos += 2; p += arg;
+        } else if (kind == WP_TOK_CACHE) {
+            if (cc_size == 0) return fail(WP_ERR_NULL, "null color cache");
+            if (arg >= cc_size) return fail(WP_ERR_FORMAT, "Invalid color cache index");
+            if (p >= total) return fail(WP_ERR_FORMAT, "token stream: more pixels than the image holds");
+            pos += 1; p += 1;
+        } else {
+            return fail(WP_ERR_FORMAT, "token stream: unknown token kind");
+        }
+    }
+    if (p != total) return fail(WP_ERR_FORMAT, "token stream: fewer pixels than the image holds");
+    return WP_OK;
+}
+
 int wp_alpha_unfilter_dev(int n, const wp_alpha_frame* fh, const wp_alpha_frame* fd, const uint8_t* d_src, uint8_t* d_alpha, void* stream) {
     int rc = ensure_init(); if (rc) return rc;
     if (n < 0 || (n > 0 && (!fh || !fd || !d_src || !d_alpha))) return fail(WP_ERR_INVALID, "bad argument");
@@ -617,6 +665,27 @@ int wp_vp8l_inverse(int n, const wp_vp8l_frame* frames, const uint8_t* pix, size
     return WP_OK;
 }
 
+int wp_vp8l_resolve(int n, const wp_vp8l_tokens_frame* frames, const uint32_t* tokens, size_t n_words, uint8_t* pix, size_t pix_len) {
+    int rc = ensure_init(); if (rc) return rc;
+    if (n < 0 || (n > 0 && (!frames || !tokens || !pix))) return fail(WP_ERR_INVALID, "bad argument");
+    if (n == 0) return WP_OK;
+    auto fits = [](uint64_t off, uint64_t extent, uint64_t len) { return off <= len && extent <= len - off; };
+    for (int i = 0; i < n; ++i) {
+        const wp_vp8l_tokens_frame& a = frames[i];
+        if (bad_tokens_frame(a)) return fail(WP_ERR_INVALID, "bad wp_vp8l_tokens_frame at index " + std::to_string(i));
+        if (!fits(a.tok_off / 4, a.n_words, n_words)) return fail(WP_ERR_INVALID, "token slab too small");
+        if (!fits(a.pix_off, uint64_t(4) * a.coded_width * a.height, pix_len)) return fail(WP_ERR_INVALID, "pix slab too small");
+        if ((rc = wp_vp8l_check_tokens(&a, tokens + a.tok_off / 4))) return rc;
+    }
+    DevBuf dfr, dtok, dpix;
+    if ((rc = dfr.upload(frames, sizeof(wp_vp8l_tokens_frame) * size_t(n))) || (rc = dtok.upload(tokens, n_words * 4)) || (rc = dpix.alloc(pix_len))) return rc;
+    rc = wp_vp8l_resolve_dev(n, frames, dfr.as<wp_vp8l_tokens_frame>(), dtok.as<uint32_t>(), dpix.as<uint8_t>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(pix, dpix.p, pix_len, hipMemcpyDeviceToHost));
+    return WP_OK;
+}
+
 int wp_alpha_unfilter(int n, const wp_alpha_frame* frames, const uint8_t* src, size_t src_len, uint8_t* alpha, size_t alpha_len) {
     int rc = ensure_init(); if (rc) return rc;
     if (n < 0 || (n > 0 && (!frames || !src || !alpha))) return fail(WP_ERR_INVALID, "bad argument");
@@ -640,7 +709,8 @@ int wp_alpha_unfilter(int n, const wp_alpha_frame* frames, const uint8_t* src, s
 }
 
 // ---- host parse objects ----
-int wp_parse(const uint8_t* data, size_t len, wp_parsed** out) {
+int wp_parse(const uint8_t* data, size_t len, wp_parsed** out) { return wp_parse_ex(data, len, 0, out); }
+int wp_parse_ex(const uint8_t* data, size_t len, int flags, wp_parsed** out) {
     if (!out) return fail(WP_ERR_INVALID, "null out pointer");
     *out = nullptr;
     if (!data && len) return fail(WP_ERR_INVALID, "null data");
@@ -649,7 +719,7 @@ int wp_parse(const uint8_t* data, size_t len, wp_parsed** out) {
     std::string err;
     int rc;
     try {                                   // no exception crosses the C ABI
-        rc = wp::parse_webp(data, len, *p, err);
+        rc = wp::parse_webp(data, len, *p, err, flags);
     } catch (const std::bad_alloc&) {
         rc = WP_ERR_NOMEM; err = "out of memory";
     } catch (const std::exception& e) {
@@ -662,6 +732,9 @@ int wp_parse(const uint8_t* data, size_t len, wp_parsed** out) {
 void wp_parsed_free(wp_parsed* p) { delete p; }
 
 int wp_parse_batch(int n, const uint8_t* const* data, const size_t* len, int n_threads, wp_parsed** out, int* status) {
+    return wp_parse_batch_ex(n, data, len, n_threads, 0, out, status);
+}
+int wp_parse_batch_ex(int n, const uint8_t* const* data, const size_t* len, int n_threads, int flags, wp_parsed** out, int* status) {
     if (n < 0 || (n > 0 && (!data || !len || !out))) return fail(WP_ERR_INVALID, "bad argument");
     if (n == 0) return WP_OK;
     if (n_threads <= 0) n_threads = int(std::max(1u, std::thread::hardware_concurrency()));
@@ -682,7 +755,7 @@ int wp_parse_batch(int n, const uint8_t* const* data, const size_t* len, int n_t
             if (!p) { st[size_t(i)] = WP_ERR_NOMEM; msg[size_t(i)] = "out of memory"; continue; }
             int rc;
             try {
-                rc = (!data[i] && len[i]) ? WP_ERR_INVALID : wp::parse_webp(data[i], len[i], *p, msg[size_t(i)]);
+                rc = (!data[i] && len[i]) ? WP_ERR_INVALID : wp::parse_webp(data[i], len[i], *p, msg[size_t(i)], flags);
             } catch (const std::exception&) {     // bad_alloc and anything else the containers throw
                 rc = WP_ERR_NOMEM; msg[size_t(i)].clear();
             }
@@ -903,7 +976,7 @@ int wp_parsed_frame_info(const wp_parsed* p, int i, int32_t* info) {
 }
 
 // which: 0 MB records, 1 filter records, 2 coefficient blocks, 3 VP8L pix, 4 raw alpha bytes, 5 alpha VP8L pix,
-//        10+k: data of VP8L transform k, 20+k: data of the alpha image's transform k
+//        6 VP8L token stream (WP_PARSE_VP8L_TOKENS), 10+k: data of VP8L transform k, 20+k: data of the alpha image's transform k
 const void* wp_parsed_frame_buf(const wp_parsed* p, int i, int which, size_t* len) {
     if (len) *len = 0;
     if (!p || i < 0 || size_t(i) >= p->frames.size()) return nullptr;
@@ -916,6 +989,7 @@ const void* wp_parsed_frame_buf(const wp_parsed* p, int i, int which, size_t* le
     case 3: return ret(f.vp8l.pix.data(), f.vp8l.pix.size());
     case 4: return ret(f.alpha.raw.data(), f.alpha.raw.size());
     case 5: return ret(f.alpha.coded.pix.data(), f.alpha.coded.pix.size());
+    case 6: return ret(f.vp8l.tokens.data(), f.vp8l.tokens.size() * 4);
     default:
         if (which >= 10 && which < 14 && size_t(which - 10) < f.vp8l.transforms.size())
             return ret(f.vp8l.transforms[size_t(which - 10)].pix.data(), f.vp8l.transforms[size_t(which - 10)].pix.size());
@@ -925,7 +999,7 @@ const void* wp_parsed_frame_buf(const wp_parsed* p, int i, int which, size_t* le
     }
 }
 
-// meta: [0] vp8l width, [1] height, [2] n_transforms, [4+3k..6+3k] (type, bits, old_width) of transform k;
+// meta: [0] vp8l width, [1] height, [2] n_transforms, [3] colour-cache bits of a tokenized image, [4+3k..6+3k] (type, bits, old_width) of transform k;
 //       [16..18] and [20+3k..22+3k]: the same for the VP8L-coded alpha image of the frame
 int wp_parsed_frame_vp8l_meta(const wp_parsed* p, int i, int32_t* meta) {
     if (!p || i < 0 || size_t(i) >= p->frames.size() || !meta) return fail(WP_ERR_INVALID, "bad frame index");
@@ -934,7 +1008,7 @@ int wp_parsed_frame_vp8l_meta(const wp_parsed* p, int i, int32_t* meta) {
     const wp::Vp8lPacked* src[2] = {&f.vp8l, &f.alpha.coded};
     for (int s = 0; s < 2; ++s) {
         int32_t* m = meta + 16 * s;
-        m[0] = src[s]->width; m[1] = src[s]->height; m[2] = int32_t(src[s]->transforms.size());
+        m[0] = src[s]->width; m[1] = src[s]->height; m[2] = int32_t(src[s]->transforms.size()); m[3] = src[s]->cc_bits;
         for (size_t k = 0; k < src[s]->transforms.size() && k < 4; ++k) {
             m[4 + 3 * k] = src[s]->transforms[k].type; m[5 + 3 * k] = src[s]->transforms[k].bits; m[6 + 3 * k] = src[s]->transforms[k].old_width;
         }

@@ -27,10 +27,15 @@ struct Vp8lPacked {
     int width = 0, height = 0;           // originalW, h
     int coded_width = 0;                 // width of `pix` rows
     std::vector<Vp8lTransform> transforms;   // bitstream order
-    std::vector<uint8_t> pix;            // RGBA, 4*coded_width*height
+    std::vector<uint8_t> pix;            // RGBA, 4*coded_width*height (empty when the image was tokenized instead)
+    // WP_PARSE_VP8L_TOKENS: the entropy-decoded symbols of the top-level image, NOT resolved into pixels (the LZ77 copies
+    // and colour-cache lookups of decodePix, Vp8LDecoder.hx:254-333, are left to wp_vp8l_resolve_dev); format in webp_amd.h
+    bool tokenized = false;
+    int cc_bits = 0;                     // colour-cache bits of the top-level image (0 = none)
+    std::vector<uint32_t> tokens;
 };
 // Input may be the concatenation of two buffers (types/ConcatInput.hx, used by readAlpha).
-int parse_vp8l(const uint8_t* a, size_t alen, const uint8_t* b, size_t blen, Vp8lPacked& out, std::string& err);
+int parse_vp8l(const uint8_t* a, size_t alen, const uint8_t* b, size_t blen, Vp8lPacked& out, std::string& err, bool tokens = false);
 
 // ALPH chunk payload after the host half of readAlpha (WebPDecoder.hx:311-355).
 struct AlphaPacked {
@@ -60,6 +65,6 @@ struct wp_parsed {
 };
 
 namespace wp {
-int parse_webp(const uint8_t* data, size_t len, wp_parsed& out, std::string& err);
+int parse_webp(const uint8_t* data, size_t len, wp_parsed& out, std::string& err, int flags = 0);
 void set_error(const std::string& msg);
 }

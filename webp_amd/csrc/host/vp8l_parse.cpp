@@ -143,7 +143,7 @@ inline int n_tiles(int dim, int bits) { return (dim + (1 << bits) - 1) >> bits; 
 
 class Vp8lParser {
 public:
-    Vp8lParser(const uint8_t* a, size_t alen, const uint8_t* b, size_t blen) : d_(a, alen, b, blen) {}
+    Vp8lParser(const uint8_t* a, size_t alen, const uint8_t* b, size_t blen, bool tokens) : d_(a, alen, b, blen), tokens_(tokens) {}
 
     void run(Vp8lPacked& out) {                                          // Vp8LDecoder.hx:347-393
         if (d_.read(8) != 0x2f) throw Fail{WP_ERR_FORMAT, "vp8l: invalid header"};
@@ -162,7 +162,12 @@ public:
             out.transforms.push_back(std::move(t));
         }
         out.coded_width = w;
-        pixels(w, h, true, out.pix);
+        if (tokens_) {
+            out.tokenized = true;
+            tokenize(w, h, out);
+        } else {
+            pixels(w, h, true, out.pix);
+        }
     }
 
 private:
@@ -253,43 +258,55 @@ private:
 
     struct Group { Huffman t[5]; };
 
-    void pixels(int w, int h, bool top, std::vector<uint8_t>& pix) {     // Vp8LDecoder.hx:185-335
-        static const int kAlphabet[5] = {256 + 24, 256, 256, 256, 40};
-        int cc_bits = 0, cc_shift = 0;
-        std::vector<uint32_t> cache;
-        if (d_.read(1)) {
-            cc_bits = int(d_.read(4));
-            if (cc_bits < 1 || cc_bits > 11) throw Fail{WP_ERR_FORMAT, "Invalid color cache parameters"};
-            cc_shift = 32 - cc_bits;
-            cache.assign(size_t(1) << cc_bits, 0);
-        }
-        int h_bits = 0, max_group = 0;
+    // What decodePix sets up before its pixel loop (Vp8LDecoder.hx:185-252): colour-cache size, the meta image that picks
+    // a Huffman group per tile, the groups themselves.
+    struct PixelCodes {
+        int cc_bits = 0;
+        int h_bits = 0, h_mask = 0, tiles_per_row = 0;
         std::vector<uint8_t> meta;
+        std::vector<Group> groups;
+        const Group* at(int x, int y) const {
+            const size_t i = size_t(4) * size_t(tiles_per_row * (y >> h_bits) + (x >> h_bits));
+            return &groups[size_t((meta[i] << 8) | meta[i + 1])];
+        }
+    };
+    void pixel_codes(int w, int h, bool top, PixelCodes& c) {
+        static const int kAlphabet[5] = {256 + 24, 256, 256, 256, 40};
+        if (d_.read(1)) {
+            c.cc_bits = int(d_.read(4));
+            if (c.cc_bits < 1 || c.cc_bits > 11) throw Fail{WP_ERR_FORMAT, "Invalid color cache parameters"};
+        }
+        int max_group = 0;
         if (top && d_.read(1)) {
-            h_bits = int(d_.read(3)) + 2;
-            pixels(n_tiles(w, h_bits), n_tiles(h, h_bits), false, meta);
-            for (size_t p = 0; p < meta.size(); p += 4) {
-                const int g = (meta[p] << 8) | meta[p + 1];
+            c.h_bits = int(d_.read(3)) + 2;
+            pixels(n_tiles(w, c.h_bits), n_tiles(h, c.h_bits), false, c.meta);
+            for (size_t p = 0; p < c.meta.size(); p += 4) {
+                const int g = (c.meta[p] << 8) | c.meta[p + 1];
                 if (g > max_group) max_group = g;
             }
         }
-        std::vector<Group> groups(size_t(max_group) + 1);
-        for (Group& g : groups)
-            for (int j = 0; j < 5; ++j) tree(g.t[j], kAlphabet[j] + ((j == 0 && cc_bits > 0) ? (1 << cc_bits) : 0));
+        c.groups.resize(size_t(max_group) + 1);
+        for (Group& g : c.groups)
+            for (int j = 0; j < 5; ++j) tree(g.t[j], kAlphabet[j] + ((j == 0 && c.cc_bits > 0) ? (1 << c.cc_bits) : 0));
+        c.h_mask = c.h_bits ? (1 << c.h_bits) - 1 : 0;
+        c.tiles_per_row = c.h_bits ? n_tiles(w, c.h_bits) : 0;
+    }
 
-        const int h_mask = h_bits ? (1 << h_bits) - 1 : 0;
-        const int tiles_per_row = h_bits ? n_tiles(w, h_bits) : 0;
+    void pixels(int w, int h, bool top, std::vector<uint8_t>& pix) {     // Vp8LDecoder.hx:185-335
+        PixelCodes c;
+        pixel_codes(w, h, top, c);
+        const int cc_shift = 32 - c.cc_bits;
+        std::vector<uint32_t> cache;
+        if (c.cc_bits) cache.assign(size_t(1) << c.cc_bits, 0);
+        const int h_mask = c.h_mask;
         const int64_t total = int64_t(4) * w * h;
         pix.assign(size_t(total), 0);
         int64_t p = 0, cached = 0;
         int x = 0, y = 0;
-        const Group* hg = &groups[0];
+        const Group* hg = &c.groups[0];
         bool lookup = h_mask != 0;
         while (p < total) {
-            if (lookup) {
-                const size_t i = size_t(4) * size_t(tiles_per_row * (y >> h_bits) + (x >> h_bits));
-                hg = &groups[size_t((meta[i] << 8) | meta[i + 1])];
-            }
+            if (lookup) hg = c.at(x, y);
             int green = hg->t[0].next(d_);
             if (green < 256) {
                 const int red = hg->t[1].next(d_);
@@ -331,14 +348,70 @@ private:
         }
     }
 
+    // The same walk over the top-level image with the symbols written down instead of acted on: literal runs, copies
+    // (length, distance in pixels) and colour-cache indices, in the token format of webp_amd.h.  Every check decodePix makes
+    // on the way (Vp8LDecoder.hx:283-289, 308-316) depends on positions and indices only, never on pixel values, so the
+    // same inputs fail here with the same messages.
+    void tokenize(int w, int h, Vp8lPacked& out) {
+        PixelCodes c;
+        pixel_codes(w, h, true, c);
+        out.cc_bits = c.cc_bits;
+        std::vector<uint32_t>& tok = out.tokens;
+        const int h_mask = c.h_mask;
+        const int64_t total = int64_t(w) * h;
+        tok.reserve(size_t(total / 2) + 16);
+        int64_t p = 0;
+        size_t run = SIZE_MAX;                   // index of the open literal run's header word
+        int x = 0, y = 0;
+        const Group* hg = &c.groups[0];
+        bool lookup = h_mask != 0;
+        while (p < total) {
+            if (lookup) hg = c.at(x, y);
+            const int green = hg->t[0].next(d_);
+            if (green < 256) {
+                const uint32_t red = uint32_t(hg->t[1].next(d_)) & 0xFF;
+                const uint32_t blue = uint32_t(hg->t[2].next(d_)) & 0xFF;
+                const uint32_t alpha = uint32_t(hg->t[3].next(d_)) & 0xFF;
+                if (run == SIZE_MAX) { run = tok.size(); tok.push_back(WP_TOK_LITERALS << 30); }
+                tok.push_back(red | uint32_t(green) << 8 | blue << 16 | alpha << 24);     // R,G,B,A in memory order
+                ++tok[run];
+                ++p;
+                if (++x == w) { x = 0; ++y; }
+                lookup = h_mask != 0 && (x & h_mask) == 0;
+            } else if (green < 256 + 24) {
+                const int length = int(lz77(uint32_t(green - 256)));
+                const int dist_code = int(lz77(uint32_t(hg->t[4].next(d_))));
+                const int dist = distance(w, dist_code);
+                if (int64_t(dist) > p || p + length > total) throw Fail{WP_ERR_FORMAT, "Invalid LZ77 parameters"};
+                run = SIZE_MAX;
+                tok.push_back(WP_TOK_COPY << 30 | uint32_t(length));
+                tok.push_back(uint32_t(dist));
+                p += length;
+                x += length;
+                while (x >= w) { x -= w; ++y; }
+                lookup = h_mask != 0;
+            } else {
+                if (c.cc_bits == 0) throw Fail{WP_ERR_NULL, "null color cache"};
+                const int index = green - (256 + 24);
+                if (index >= (1 << c.cc_bits)) throw Fail{WP_ERR_FORMAT, "Invalid color cache index"};
+                run = SIZE_MAX;
+                tok.push_back(WP_TOK_CACHE << 30 | uint32_t(index));
+                ++p;
+                if (++x == w) { x = 0; ++y; }
+                lookup = h_mask != 0 && (x & h_mask) == 0;
+            }
+        }
+    }
+
     BitSource d_;
+    bool tokens_;
 };
 
 }  // namespace
 
-int parse_vp8l(const uint8_t* a, size_t alen, const uint8_t* b, size_t blen, Vp8lPacked& out, std::string& err) {
+int parse_vp8l(const uint8_t* a, size_t alen, const uint8_t* b, size_t blen, Vp8lPacked& out, std::string& err, bool tokens) {
     try {
-        Vp8lParser p(a, alen, b, blen);
+        Vp8lParser p(a, alen, b, blen, tokens);
         p.run(out);
     } catch (const Fail& f) {
         err = f.msg;

@@ -41,7 +41,7 @@ int parse_alpha(const uint8_t* d, size_t n, int wm1, int hm1, int flags, AlphaPa
 }
 
 // readFrameData, WebPDecoder.hx:258-309
-int parse_frame_data(const uint8_t* d, size_t len, size_t pos, int wm1, int hm1, ParsedFrame& fr, std::string& err) {
+int parse_frame_data(const uint8_t* d, size_t len, size_t pos, int wm1, int hm1, ParsedFrame& fr, std::string& err, int flags) {
     bool lossy = false, lossless = false;
     while (pos < len) {
         if (len - pos < 8) break;
@@ -66,7 +66,7 @@ int parse_frame_data(const uint8_t* d, size_t len, size_t pos, int wm1, int hm1,
             lossy = true;
         } else if (tag(id, "VP8L")) {
             fr.vp8l = Vp8lPacked();
-            const int rc = parse_vp8l(cd, size_t(n), nullptr, 0, fr.vp8l, err);
+            const int rc = parse_vp8l(cd, size_t(n), nullptr, 0, fr.vp8l, err, (flags & WP_PARSE_VP8L_TOKENS) != 0);
             if (rc) return rc;
             lossless = true;
         }
@@ -79,7 +79,7 @@ int parse_frame_data(const uint8_t* d, size_t len, size_t pos, int wm1, int hm1,
 
 }  // namespace
 
-int parse_webp(const uint8_t* data, size_t len, wp_parsed& out, std::string& err) {
+int parse_webp(const uint8_t* data, size_t len, wp_parsed& out, std::string& err, int flags) {
     // readRiffHeader :37-45
     if (len < 4) { err = "Eof"; return WP_ERR_EOF; }
     if (!tag(data, "RIFF")) { err = "Missing RIFF chunk header"; return WP_ERR_FORMAT; }
@@ -123,7 +123,7 @@ int parse_webp(const uint8_t* data, size_t len, wp_parsed& out, std::string& err
             lossy = true;
         } else if (tag(id, "VP8L")) {                           // readVp8l :105-131
             still.vp8l = Vp8lPacked();
-            const int rc = parse_vp8l(cd, size_t(n), nullptr, 0, still.vp8l, err);
+            const int rc = parse_vp8l(cd, size_t(n), nullptr, 0, still.vp8l, err, (flags & WP_PARSE_VP8L_TOKENS) != 0);
             if (rc) return rc;
             lossless = true;
         } else if (tag(id, "ANIM")) {                           // readAnim :143-148
@@ -132,7 +132,7 @@ int parse_webp(const uint8_t* data, size_t len, wp_parsed& out, std::string& err
             if (n < 16) { err = "Eof"; return WP_ERR_EOF; }
             ParsedFrame fr;
             const int fwm1 = le24(cd + 6), fhm1 = le24(cd + 9);
-            const int rc = parse_frame_data(cd, size_t(n), 16, fwm1, fhm1, fr, err);
+            const int rc = parse_frame_data(cd, size_t(n), 16, fwm1, fhm1, fr, err, flags);
             if (rc) return rc;
             fr.x = le24(cd); fr.y = le24(cd + 3);
             fr.width = fwm1 + 1; fr.height = fhm1 + 1;

@@ -1,0 +1,136 @@
+// The pixel loop of decodePix on the device (Vp8LDecoder.hx:254-333): literal stores (:283-290), LZ77 copies (:308-316)
+// and the lazily filled colour cache (:320-333), driven by the token stream the host's Huffman decode leaves
+// (include/webp_amd.h, wp_vp8l_tokens_frame).  The loop is serial in the tokens but wide inside one: a literal run or a
+// copy of n pixels is n independent lanes (a copy whose distance is shorter than its length repeats its source with
+// period `dist`, so every lane still reads a pixel that existed before the token), and filling the cache with the pixels
+// since the last lookup is one hash per lane with "the latest pixel wins" settled by an LDS atomic max on the pixel index.
+//
+// One wavefront per image.  The last 16384 pixels it wrote stay in an LDS ring, which serves every copy whose distance
+// is below 12224 pixels (the distance codes 1..120 reach 7 rows up: all of them for images up to 1746 pixels wide) and
+// the cache fill; longer distances re-read the output slab from L2 after a release fence.  Token words are fetched 64 at
+// a time into one register per lane and walked with v_readlane, so a token costs no memory round trip unless it is a long
+// literal run.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include "../../../include/webp_amd.h"
+
+namespace wpk {
+
+constexpr uint32_t kRingPx = 16384, kRingMask = kRingPx - 1;
+constexpr uint32_t kCopyPiece = 4096;                       // the longest copy the bitstream can code (Vp8LDecoder.hx:337-345); longer ones are taken in pieces
+constexpr uint32_t kRingReach = kRingPx - kCopyPiece - 64;  // copies up to this distance never see a ring slot reused under them
+constexpr int kMaxCacheBits = 11;                           // Vp8LDecoder.hx:228
+
+__device__ __forceinline__ uint32_t lane_word(uint32_t v, uint32_t l) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(l))); }
+__device__ __forceinline__ uint32_t far_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// key of a pixel: the reference hashes A<<24 | R<<16 | G<<8 | B (Vp8LDecoder.hx:323-326); pixels are kept as R,G,B,A bytes
+__device__ __forceinline__ uint32_t cache_hash(uint32_t rgba) {
+    const uint32_t argb = (rgba & 0xff00ff00u) | ((rgba & 0xffu) << 16) | ((rgba >> 16) & 0xffu);
+    return argb * 0x1e35a7bdu;
+}
+
+__global__ __launch_bounds__(64)
+void vp8l_resolve_kernel(const wp_vp8l_tokens_frame* __restrict__ frames, const uint32_t* __restrict__ tokens, uint8_t* pix_slab) {
+    __shared__ uint32_t ring[kRingPx];
+    __shared__ uint32_t cval[1 << kMaxCacheBits];
+    __shared__ uint32_t cown[1 << kMaxCacheBits];           // 1 + index of the pixel that owns the entry
+    const wp_vp8l_tokens_frame fr = frames[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t* tok = tokens + (fr.tok_off >> 2);
+    uint32_t* out = reinterpret_cast<uint32_t*>(pix_slab + fr.pix_off);
+    const uint32_t total = uint32_t(fr.coded_width) * uint32_t(fr.height);
+    const uint32_t n_words = uint32_t(fr.n_words);          // the launcher refuses streams of 2^32 words and more
+    const uint32_t cc_size = fr.cc_bits > 0 ? 1u << fr.cc_bits : 0u;
+    const int cc_shift = 32 - fr.cc_bits;
+    for (uint32_t i = lane; i < cc_size; i += 64) { cval[i] = 0; cown[i] = 0; }
+
+    uint32_t pos = 0, p = 0, cached = 0;
+    uint32_t blk_base = 0, blk = lane < n_words ? tok[lane] : 0u;
+    while (pos < n_words && p < total) {
+        if (pos - blk_base >= 64u) { blk_base = pos; blk = (lane < n_words - pos) ? tok[pos + lane] : 0u; }
+        const uint32_t t = lane_word(blk, pos - blk_base);
+        const uint32_t kind = t >> 30, arg = t & 0x3fffffffu;
+        if (kind == WP_TOK_LITERALS) {
+            const uint32_t first = pos + 1;
+            const uint32_t n = min(min(arg, total - p), n_words - first);
+            if (first - blk_base + n <= 64u) {               // the payload is in the block already
+                const uint32_t w = uint32_t(__builtin_amdgcn_ds_bpermute(int(4u * (first - blk_base + lane)), int(blk)));
+                if (lane < n) { ring[(p + lane) & kRingMask] = w; out[p + lane] = w; }
+            } else {
+                for (uint32_t c = 0; c < n; c += 64) {
+                    const uint32_t i = c + lane;
+                    if (i < n) { const uint32_t w = tok[first + i]; ring[(p + i) & kRingMask] = w; out[p + i] = w; }
+                }
+            }
+            p += n;
+            if (n != arg) break;                             // malformed: the run leaves the image or the stream
+            pos = first + n;
+        } else if (kind == WP_TOK_COPY) {
+            if (n_words - pos < 2u) break;
+            const uint32_t at = pos + 1 - blk_base;
+            const uint32_t dist = at < 64u ? lane_word(blk, at) : uint32_t(__builtin_amdgcn_readfirstlane(int(tok[pos + 1])));
+            if (dist == 0 || dist > p || arg > total - p) break;        // "Invalid LZ77 parameters" (the host has refused these)
+            uint32_t len = arg;
+            while (len) {
+                const uint32_t l = min(len, kCopyPiece);
+                const uint32_t src0 = p - dist;
+                const bool periodic = dist < l;
+                if (dist <= kRingReach) {
+                    for (uint32_t c = 0; c < l; c += 64) {
+                        const uint32_t i = c + lane;
+                        if (i < l) {
+                            const uint32_t w = ring[(src0 + (periodic ? i % dist : i)) & kRingMask];
+                            ring[(p + i) & kRingMask] = w;
+                            out[p + i] = w;
+                        }
+                    }
+                } else {                                     // dist > kRingReach > l: plain forward copy out of the slab
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    for (uint32_t c = 0; c < l; c += 64) {
+                        const uint32_t i = c + lane;
+                        if (i < l) {
+                            const uint32_t w = far_load(out + src0 + i);
+                            ring[(p + i) & kRingMask] = w;
+                            out[p + i] = w;
+                        }
+                    }
+                }
+                p += l;
+                len -= l;
+            }
+            pos += 2;
+        } else if (kind == WP_TOK_CACHE) {
+            if (arg >= cc_size) break;                        // "Invalid color cache index" / "null color cache"
+            // the pixels written since the last lookup enter the cache now, in order (Vp8LDecoder.hx:320-327)
+            for (uint32_t b = cached; b < p; b += 64) {
+                const uint32_t idx = b + lane;
+                const bool active = idx < p;
+                uint32_t w = 0;
+                if (p - b <= kRingPx) {
+                    if (active) w = ring[idx & kRingMask];
+                } else {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (active) w = far_load(out + idx);
+                }
+                const uint32_t key = cache_hash(w) >> cc_shift;
+                if (active) atomicMax(&cown[key], idx + 1);
+                if (active && *static_cast<volatile uint32_t*>(&cown[key]) == idx + 1) cval[key] = w;
+            }
+            cached = p;
+            const uint32_t w = *static_cast<volatile uint32_t*>(&cval[arg]);
+            if (lane == 0) { ring[p & kRingMask] = w; out[p] = w; }
+            p += 1;
+            pos += 1;
+        } else {
+            break;
+        }
+    }
+}
+
+}  // namespace wpk
+
+extern "C" int wpk_launch_vp8l_resolve(int n, const wp_vp8l_tokens_frame* d_frames, const uint32_t* d_tokens, uint8_t* d_pix, hipStream_t stream) {
+    hipLaunchKernelGGL(wpk::vp8l_resolve_kernel, dim3(n), dim3(64), 0, stream, d_frames, d_tokens, d_pix);
+    return int(hipGetLastError());
+}

@@ -98,7 +98,7 @@ class ParsedFrame:
         self._owner = owner
         self._index = index
 
-    _VP8L_META = ("vp8l_width", "vp8l_height", "transforms", "alpha_width", "alpha_height", "alpha_transforms")
+    _VP8L_META = ("vp8l_width", "vp8l_height", "transforms", "alpha_width", "alpha_height", "alpha_transforms", "cc_bits")
 
     def __getattr__(self, name):          # only called when normal lookup fails
         if name in ParsedFrame._VP8L_META:
@@ -116,11 +116,11 @@ class ParsedFrame:
 
 
 class ParsedFile:
-    def __init__(self, data: bytes = None, handle=None):
+    def __init__(self, data: bytes = None, handle=None, vp8l_tokens=False):
         L = lib()
         if handle is None:
             h = ctypes.c_void_p()
-            check(L.wp_parse(data, len(data), ctypes.byref(h)))
+            check(L.wp_parse_ex(data, len(data), 1 if vp8l_tokens else 0, ctypes.byref(h)))
         else:
             h = ctypes.c_void_p(handle)
         self._h = h
@@ -138,12 +138,14 @@ class ParsedFile:
             pass
 
 
-def parse(data: bytes) -> ParsedFile:
-    """Container walk + entropy decode on the CPU (mirrors the parse half of WebPDecoder.decode)."""
-    return ParsedFile(data)
+def parse(data: bytes, vp8l_tokens: bool = False) -> ParsedFile:
+    """Container walk + entropy decode on the CPU (mirrors the parse half of WebPDecoder.decode).  vp8l_tokens: leave the
+    pixel loop of decodePix (literal stores, LZ77 copies, colour cache: Vp8LDecoder.hx:283-333) of every VP8L image to the
+    device (wp_vp8l_resolve_dev); the host then stops after the Huffman decode and hands over the token stream."""
+    return ParsedFile(data, vp8l_tokens=vp8l_tokens)
 
 
-def parse_many(datas: List[bytes], threads: int = 0, strict: bool = True) -> List[ParsedFile]:
+def parse_many(datas: List[bytes], threads: int = 0, strict: bool = True, vp8l_tokens: bool = False) -> List[ParsedFile]:
     """parse() for a list of files on `threads` native host threads (0 = all hardware threads).  strict: raise on the first
     bad file (what a loop over WebPDecoder.decode would do); otherwise a bad file fails alone: its slot holds the WebPError
     the reference would have thrown for it and every other file is parsed."""
@@ -155,7 +157,7 @@ def parse_many(datas: List[bytes], threads: int = 0, strict: bool = True) -> Lis
     lens = (ctypes.c_size_t * n)(*[len(d) for d in datas])
     out = (ctypes.c_void_p * n)()
     status = (ctypes.c_int * n)()
-    rc = L.wp_parse_batch(n, ptrs, lens, threads, out, status)
+    rc = L.wp_parse_batch_ex(n, ptrs, lens, threads, 1 if vp8l_tokens else 0, out, status)
     files = [ParsedFile(handle=out[i]) if out[i] else None for i in range(n)]     # owns (and frees) whatever did parse
     if strict:
         check(rc)
@@ -163,7 +165,7 @@ def parse_many(datas: List[bytes], threads: int = 0, strict: bool = True) -> Lis
     for i in range(n):
         if files[i] is None:                 # re-parse the bad one alone to get ITS message (wp_last_error holds the first one's only)
             try:
-                files[i] = ParsedFile(datas[i])
+                files[i] = ParsedFile(datas[i], vp8l_tokens=vp8l_tokens)
             except _lib.WebPError as e:
                 files[i] = e
     return files
@@ -271,19 +273,22 @@ _TRANSFORM_BUF0 = 10
 
 class LosslessBatch:
     """Packed slabs for a list of VP8L images (wp_vp8l_inverse[_dev]).  `which_pix`/`which_t0` select the
-    frame's own image (3 / 10) or its VP8L-coded alpha image (5 / 20)."""
+    frame's own image (3 / 10) or its VP8L-coded alpha image (5 / 20).  Frames parsed with vp8l_tokens=True bring a token
+    stream instead of pixels: their part of the pix slab is left for wp_vp8l_resolve[_dev] to fill (tok_desc / tokens,
+    n_tok frames; resolve() does it through the host-pointer entry point)."""
 
     def __init__(self, frames: List[ParsedFrame], alpha_image=False):
         n = len(frames)
         self.n = n
         self.desc = (Vp8lFrame * max(n, 1))()
         which_pix, which_t0 = (5, 20) if alpha_image else (3, _TRANSFORM_BUF0)
-        pix, aux = [], []
-        pix_off = aux_off = out_off = 0
+        pix, aux, toks, tdesc = [], [], [], []
+        pix_off = aux_off = out_off = tok_off = 0
         L = lib()
         for i, f in enumerate(frames):
             d = self.desc[i]
             p = f.buf(which_pix)
+            tk = f.buf(6, np.uint32) if not alpha_image else np.zeros(0, np.uint32)
             if alpha_image:
                 width, height = f.alpha_width, f.alpha_height
             else:
@@ -305,6 +310,11 @@ class LosslessBatch:
                 aux_off += data.size + pad
                 if ttype == 3:
                     coded_width = (old_width + (1 << bits) - 1) >> bits
+            if tk.size:
+                p = np.zeros(4 * coded_width * height, np.uint8)
+                tdesc.append((coded_width, height, f.cc_bits, tok_off, tk.size, pix_off))
+                toks.append(tk)
+                tok_off += 4 * tk.size
             d.coded_width = p.size // (4 * height) if height else 0
             assert d.coded_width == coded_width, (d.coded_width, coded_width)
             pix.append(p)
@@ -318,6 +328,17 @@ class LosslessBatch:
         if self.aux.size == 0:
             self.aux = np.zeros(16, np.uint8)
         self.out_bytes = max(out_off, 16)
+        self.n_tok = len(tdesc)
+        self.tok_desc = (_lib.Vp8lTokensFrame * max(self.n_tok, 1))()
+        for k, (cw, hh, cc, to, nw, po) in enumerate(tdesc):
+            t = self.tok_desc[k]
+            t.coded_width, t.height, t.cc_bits, t.tok_off, t.n_words, t.pix_off = cw, hh, cc, to, nw, po
+        self.tokens = np.concatenate(toks) if toks else np.zeros(4, np.uint32)
+
+    def resolve(self):
+        """decodePix's pixel loop for the tokenized frames, on the device, through the host-pointer entry point."""
+        if self.n_tok:
+            check(lib().wp_vp8l_resolve(self.n_tok, self.tok_desc, _np_ptr(self.tokens), self.tokens.size, _np_ptr(self.pix), self.pix.size))
 
 
 def _np_ptr(a):
@@ -336,6 +357,7 @@ def _load_vp8l_meta(f: ParsedFrame):
     meta = (ctypes.c_int32 * 32)()
     check(L.wp_parsed_frame_vp8l_meta(f._owner._h, f._index, meta))
     f.vp8l_width, f.vp8l_height, nt = int(meta[0]), int(meta[1]), int(meta[2])
+    f.cc_bits = int(meta[3])
     f.transforms = [(int(meta[4 + 3 * k]), int(meta[5 + 3 * k]), int(meta[6 + 3 * k])) for k in range(nt)]
     f.alpha_width, f.alpha_height, nat = int(meta[16]), int(meta[17]), int(meta[18])
     f.alpha_transforms = [(int(meta[20 + 3 * k]), int(meta[21 + 3 * k]), int(meta[22 + 3 * k])) for k in range(nat)]
@@ -418,6 +440,7 @@ def decode_batch(files: List[ParsedFile]):
     lossless = [t for t in flat if t[2].type == 1]
     if lossless:
         lb = LosslessBatch([t[2] for t in lossless])
+        lb.resolve()
         out = np.empty(lb.out_bytes, np.uint8)
         check(L.wp_vp8l_inverse(lb.n, lb.desc, _np_ptr(lb.pix), lb.pix.size, _np_ptr(lb.aux), lb.aux.size,
                                 _np_ptr(out), out.size, 1))
