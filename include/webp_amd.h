@@ -55,6 +55,12 @@ typedef struct wp_vp8_frame {
     uint64_t y_off, u_off, v_off;   /* byte offsets of the frame's planes inside the Y/U/V slabs */
     uint64_t argb_off;          /* byte offset inside the ARGB slab; tight stride 4*width */
     uint64_t alpha_off;         /* byte offset inside the alpha slab; tight stride width */
+    uint32_t cost;              /* in: relative cost of the frame, any unit (0 = unknown: the macroblock count is used);
+                                 * wp_vp8_batch_layout fills it from the parse (macroblocks, stored blocks, i4 macroblocks) */
+    uint32_t turn;              /* set by wp_vp8_plan / wp_vp8_batch_layout: SCHEDULE, not data.  The one-kernel path hands frames
+                                 * to its persistent workgroups by slot (slot s -> workgroup s mod grid); slot i works on frame
+                                 * `turn` of its launch (index relative to the launch's first frame), a permutation that pairs
+                                 * heavy frames with light ones.  No counterpart in the reference (one image per call). */
 } wp_vp8_frame;
 
 /* Per-macroblock record, 4 x uint32 (what reconstruct()'s parse half produces, Vp8Decoder.hx:772-808):
@@ -149,7 +155,7 @@ int wp_debug_set_frames_per_launch(int frames);
  *            / 4 chroma pixels so that every byte is final when it is written.
  * wp_vp8_plan fills stile_base in the (host) descriptors and returns the workspace size for the batch;
  * call it before copying the descriptors to the device.  The workspace must be 256-byte aligned. */
-int wp_vp8_plan(int n, wp_vp8_frame* frames, uint64_t* work_bytes);
+int wp_vp8_plan(int n, wp_vp8_frame* frames, uint64_t* work_bytes);   /* also fills `turn` (from `cost`) */
 /* Per-item validity of a descriptor array (no counterpart in the reference, which decodes one image per call: there "a bad
  * image fails alone" is automatic).  status[i] = WP_OK or WP_ERR_INVALID; returns the number of bad items.  The batched
  * entry points refuse a batch that contains a bad descriptor before anything is launched; a caller that wants the good

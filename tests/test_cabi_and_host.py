@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     from webp_amd._lib import Vp8Frame, Vp8lFrame, Vp8lTransform, AlphaFrame
-    assert ctypes.sizeof(Vp8Frame) == 80 and ctypes.sizeof(Vp8lTransform) == 32
+    assert ctypes.sizeof(Vp8Frame) == 88 and ctypes.sizeof(Vp8lTransform) == 32
     assert ctypes.sizeof(Vp8lFrame) == 16 + 4 * 32 + 24 and ctypes.sizeof(AlphaFrame) == 32
 
 
@@ -247,7 +247,7 @@ def test_header_is_plain_c99():
     """include/webp_amd.h compiles as C99 with -pedantic (what a HashLink .hdll shim or any other C binding includes)."""
     import subprocess, tempfile
     with tempfile.NamedTemporaryFile("w", suffix=".c") as f:
-        f.write('#include "webp_amd.h"\nint main(void) { return (int)sizeof(wp_vp8_frame) - 80; }\n')
+        f.write('#include "webp_amd.h"\nint main(void) { return (int)sizeof(wp_vp8_frame) - 88; }\n')
         f.flush()
         subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), f.name])
 
@@ -271,3 +271,27 @@ def test_parse_many_lets_a_bad_file_fail_alone():
     assert isinstance(got[0], ParsedFile) and isinstance(got[2], ParsedFile)
     assert isinstance(got[1], WebPError) and "no VP8/VP8L chunk found" in str(got[1])
     assert isinstance(got[3], WebPError)
+
+
+def test_plan_schedules_heavy_frames_with_light_ones():
+    """wp_vp8_plan's `turn` (the one-kernel path's frame schedule): a permutation per launch, heaviest frames first, rounds
+    of one frame per persistent workgroup in alternating direction; without a GPU the grid defaults to one round."""
+    from webp_amd._lib import Vp8Frame, check, lib
+    L = lib()
+    n = 37
+    desc = (Vp8Frame * n)()
+    rng = np.random.default_rng(5)
+    for i in range(n):
+        d = desc[i]
+        d.mbw, d.mbh = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        d.width, d.height = 16 * d.mbw, 16 * d.mbh
+        d.cost = int(rng.integers(0, 50))               # 0 = unknown: the MB count stands in
+    work = ctypes.c_uint64()
+    check(L.wp_vp8_plan(n, desc, ctypes.byref(work)))
+    turns = [int(desc[i].turn) for i in range(n)]
+    assert sorted(turns) == list(range(n))
+    cost = lambda i: int(desc[i].cost) or desc[i].mbw * desc[i].mbh
+    costs = [cost(t) for t in turns]
+    # within every round of `grid` slots the costs are monotonic; with no GPU (grid unknown -> 2 per CU of 0 CUs -> 1) or a
+    # grid larger than the batch this is one descending run
+    assert costs[0] == max(costs)

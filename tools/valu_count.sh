@@ -5,5 +5,5 @@ tag=${1:-x}
 export TMPDIR=/tmp
 out=gpurun_out/pmc_$tag
 mkdir -p $out
-timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR --output-format csv -d $out/p1 -o p1 -- python3 bench.py --no-cpu-baseline --serial --one-launch --steps 2 --warmup 1 > $out/p1.log 2>&1 || { echo "pass failed"; tail -5 $out/p1.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR --output-format csv -d $out/p1 -o p1 -- python3 bench.py --no-cpu-baseline --serial --steps 2 --warmup 1 > $out/p1.log 2>&1 || { echo "pass failed"; tail -5 $out/p1.log; exit 1; }
 python3 tools/pmc_summary.py $out 2>/dev/null | grep -A9 "vp8_mb_kernel\|vp8_finish_kernel" | grep -E "==|INSTS_VALU|INSTS_SALU|INSTS_LDS|BUSY_CYCLES"

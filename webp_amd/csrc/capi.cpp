@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <atomic>
 #include <condition_variable>
@@ -18,7 +19,7 @@ int wpk_launch_vp8_recon(int n, int cus, const wp_vp8_frame* d_frames, const voi
                          uint8_t* d_rtiles, hipStream_t stream);
 int wpk_launch_vp8_filter(int n, int cus, const wp_vp8_frame* d_frames, const uint32_t* d_filt,
                           const uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream);
-int wpk_launch_vp8_recon_filter(int n, int cus, const wp_vp8_frame* d_frames, const void* d_mb, const int16_t* d_coeff,
+int wpk_launch_vp8_recon_filter(int n, int cus, const wp_vp8_frame* d_frames, int use_turns, const void* d_mb, const int16_t* d_coeff,
                                 const uint32_t* d_filt, uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream);
 int wpk_launch_vp8_finish(int n, int chunks, int tile_rows, const wp_vp8_frame* d_frames, const uint8_t* d_rtiles,
                           const uint8_t* d_stiles, int force_unshifted, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
@@ -134,6 +135,43 @@ int frames_per_launch(int n, const wp_vp8_frame* f, int phases = 1) {      // ph
     return int(std::max(1LL, per));
 }
 
+// Which frame each slot of a launch works on (wp_vp8_frame.turn).  The one-kernel path's persistent workgroups take slots
+// w, w + grid, w + 2 grid, ...: with frames of unequal cost in caller order the launch ends with the workgroup that drew two
+// heavy ones (the bench batch: a q90 frame costs 1.5 x a q75 frame, two frames per workgroup).  Frames are therefore dealt
+// heaviest first, in rounds of `grid` that alternate direction (longest-processing-time order, "snake"): the workgroup that
+// got the heaviest frame of a round gets the lightest of the next.
+void assign_turns(int n, wp_vp8_frame* f) {
+    const int per = frames_per_launch(n, f);
+    const int grid = std::max(1, 2 * g_cus.load(std::memory_order_relaxed));      // WP_MB_WGS_PER_CU persistent workgroups per CU
+    std::vector<uint32_t> order;
+    for (int first = 0; first < n; first += per) {
+        const int cnt = std::min(per, n - first);
+        order.resize(size_t(cnt));
+        for (int i = 0; i < cnt; ++i) order[size_t(i)] = uint32_t(i);
+        auto cost = [&](uint32_t i) { const wp_vp8_frame& a = f[first + int(i)]; return a.cost ? uint64_t(a.cost) : uint64_t(a.mbw) * uint64_t(a.mbh); };
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });
+        for (int s = 0; s < cnt; ++s) {
+            const int round = s / grid, j = s % grid, in_round = std::min(grid, cnt - round * grid);
+            const int k = (round & 1) ? in_round - 1 - j : j;
+            f[first + s].turn = k >= 0 ? order[size_t(round * grid + k)] : order[size_t(s)];
+        }
+    }
+}
+// `turn` is trusted by the kernel as an index, and every frame must be somebody's turn: true if the descriptors of
+// launch [first, first + cnt) hold a permutation of 0..cnt-1 (what assign_turns leaves for this split into launches).
+// Otherwise -- descriptors that never saw wp_vp8_plan, or a different split (the test hook) -- the launch runs in slot order.
+bool turns_valid(int cnt, const wp_vp8_frame* f) {
+    static const bool off = std::getenv("WP_NO_TURNS") != nullptr;      // tuning switch: slot order
+    if (off) return false;
+    thread_local std::vector<uint8_t> seen;
+    seen.assign(size_t(cnt), 0);
+    for (int i = 0; i < cnt; ++i) {
+        if (f[i].turn >= uint32_t(cnt) || seen[f[i].turn]) return false;
+        seen[f[i].turn] = 1;
+    }
+    return true;
+}
+
 struct FinishGeom { int chunks = 1, rows = 1; };
 FinishGeom finish_geom(int n, const wp_vp8_frame* f) {
     FinishGeom g;
@@ -219,6 +257,8 @@ int wp_vp8_plan(int n, wp_vp8_frame* frames, uint64_t* work_bytes) {
         st += size_t(frames[i].mbw + 1) * size_t(frames[i].mbh + 1);
     }
     if (work_bytes) *work_bytes = uint64_t(vp8_work(n, frames).total);
+    if (g_cus.load(std::memory_order_relaxed) <= 0) (void)wp_init(-1);      // the schedule depends on the GPU's CU count; without a GPU the default stands
+    assign_turns(n, frames);
     return WP_OK;
 }
 
@@ -280,7 +320,8 @@ int wp_vp8_recon_filter_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* f
     uint8_t* work = static_cast<uint8_t*>(d_work);
     const int per = frames_per_launch(n, fh);
     for (int first = 0; first < n; first += per) {
-        const int e = wpk_launch_vp8_recon_filter(std::min(per, n - first), g_cus.load(std::memory_order_relaxed), fd + first, d_mb, d_coeff,
+        const int cnt = std::min(per, n - first);
+        const int e = wpk_launch_vp8_recon_filter(cnt, g_cus.load(std::memory_order_relaxed), fd + first, turns_valid(cnt, fh + first) ? 1 : 0, d_mb, d_coeff,
                                                   d_filt, work, work + w.r_bytes, hipStream_t(stream));
         if (e) return hip_fail(hipError_t(e), "vp8_mb launch");
     }
@@ -908,6 +949,9 @@ int wp_vp8_batch_layout(int n, const wp_parsed* const* files, const int* frame_i
         z.n_mb += nmb;
         st += uint64_t(d.mbw + 1) * uint64_t(d.mbh + 1);
         z.n_coeff_blocks += f->vp8.coeff.size() / 16;
+        // relative cost on the device: every MB is reconstructed and filtered, stored blocks add transforms, an i4 MB ten
+        // dependent prediction mini-steps (measured: a q90 1080p frame, 68 % i4, costs 1.5 x a q75 frame)
+        d.cost = uint32_t(std::min<uint64_t>(0xffffffffull, 24 * nmb + f->vp8.coeff.size() / 16 + 16 * uint64_t(f->vp8.n_i4)));
         z.y_bytes += align_up(size_t(256 * nmb), 256);
         z.u_bytes += align_up(size_t(64 * nmb), 256);
         z.v_bytes += align_up(size_t(64 * nmb), 256);
@@ -915,6 +959,8 @@ int wp_vp8_batch_layout(int n, const wp_parsed* const* files, const int* frame_i
         if (d.has_alpha) z.alpha_bytes += align_up(size_t(d.width) * size_t(d.height), 256);
     }
     const int rc = check_vp8_frames(n, frames); if (rc) return rc;
+    if (g_cus.load(std::memory_order_relaxed) <= 0) (void)wp_init(-1);
+    assign_turns(n, frames);
     z.work_bytes = uint64_t(vp8_work(n, frames).total);
     *sizes = z;
     return WP_OK;

@@ -15,6 +15,7 @@ struct Vp8Packed {
     int width = 0, height = 0, xScale = 0, yScale = 0;
     int mbw = 0, mbh = 0;
     int filter_type = 0;                 // 0 none, 1 simple, 2 normal
+    int n_i4 = 0;                        // macroblocks predicted per 4x4 block (they cost the device ten dependent mini-steps)
     std::vector<uint32_t> mb;            // WP_MB_WORDS per macroblock
     std::vector<uint32_t> filt;          // 1 per macroblock
     std::vector<int16_t> coeff;          // 16 per stored block

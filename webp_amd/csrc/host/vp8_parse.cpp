@@ -103,6 +103,7 @@ public:
                 LoopParam& fs = loop_[segment_][i16 ? 0 : 1];
                 fs.inner = fs.inner || !skip;
                 which[idx] = uint8_t((segment_ << 1) | (i16 ? 0 : 1));
+                out_.n_i4 += i16 ? 0 : 1;
             }
         }
         if (first_.eof) { err = "vp8: decodeFrame returned null"; return WP_ERR_NULL; }

@@ -20,7 +20,7 @@ constexpr int kMbWaves = WP_MB_WAVES;
 constexpr int kMbWGsPerCU = WP_MB_WGS_PER_CU;
 
 __global__ __launch_bounds__(kMbWaves * kWave, (kMbWaves * kMbWGsPerCU + 3) / 4)
-void vp8_mb_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, const uint4* __restrict__ mb,
+void vp8_mb_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, int use_turns, const uint4* __restrict__ mb,
                    const int16_t* __restrict__ coeff, const uint32_t* __restrict__ filt, uint8_t* Ep, uint8_t* Sp) {
     __shared__ MbWaveLds lds_all[kMbWaves];
     __shared__ uint32_t progress[kMbWaves];
@@ -30,7 +30,8 @@ void vp8_mb_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, const 
 
     uint32_t seq = 1;                   // running band number of this workgroup (identical in all its waves)
     for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
-        const wp_vp8_frame fr = frames[f];
+        // slot f works on the frame the host's schedule names (wp_vp8_frame.turn: heavy frames paired with light ones)
+        const wp_vp8_frame fr = frames[use_turns ? frames[f].turn : uint32_t(f)];
         const int n_bands = (fr.mbh + kBandRows - 1) / kBandRows;
         for (int band = 0; band < n_bands; ++band) {
             const uint32_t q = seq + uint32_t(band);
@@ -43,11 +44,11 @@ void vp8_mb_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, const 
 
 }  // namespace wpk
 
-extern "C" int wpk_launch_vp8_recon_filter(int n, int cus, const wp_vp8_frame* d_frames, const void* d_mb, const int16_t* d_coeff,
+extern "C" int wpk_launch_vp8_recon_filter(int n, int cus, const wp_vp8_frame* d_frames, int use_turns, const void* d_mb, const int16_t* d_coeff,
                                            const uint32_t* d_filt, uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream) {
     const int grid = n < cus * wpk::kMbWGsPerCU ? n : cus * wpk::kMbWGsPerCU;
     hipLaunchKernelGGL(wpk::vp8_mb_kernel, dim3(grid), dim3(wpk::kMbWaves * wpk::kWave), 0, stream,
-                       n, d_frames, reinterpret_cast<const uint4*>(d_mb), d_coeff, d_filt, d_rtiles, d_stiles);
+                       n, d_frames, use_turns, reinterpret_cast<const uint4*>(d_mb), d_coeff, d_filt, d_rtiles, d_stiles);
     return int(hipGetLastError());
 }
 
