@@ -38,6 +38,12 @@ HL_PRIM int HL_NAME(alpha_unfilter)(int n, vbyte* frames, vbyte* src, int src_le
     return wp_alpha_unfilter(n, (const wp_alpha_frame*)frames, src, (size_t)src_len, alpha, (size_t)alpha_len);
 }
 
+/* decodePix's pixel loop (Vp8LDecoder.hx:283-333) over the token stream a `-D webp_gpu` Vp8LDecoder records instead of
+ * acting on its Huffman reads: wp_vp8l_tokens_frame = 40 bytes, tokens = 32-bit words */
+HL_PRIM int HL_NAME(vp8l_resolve)(int n, vbyte* frames, vbyte* tokens, int n_words, vbyte* pix, int pix_len) {
+    return wp_vp8l_resolve(n, (const wp_vp8l_tokens_frame*)frames, (const uint32_t*)tokens, (size_t)n_words, pix, (size_t)pix_len);
+}
+
 DEFINE_PRIM(_I32, init, _I32);
 DEFINE_PRIM(_I32, shutdown, _NO_ARG);
 DEFINE_PRIM(_I32, device_count, _NO_ARG);
@@ -48,3 +54,4 @@ DEFINE_PRIM(_I32, vp8_loopfilter, _I32 _BYTES _BYTES _I32 _BYTES _BYTES _BYTES);
 DEFINE_PRIM(_I32, yuv420_to_argb, _I32 _BYTES _BYTES _BYTES _BYTES _BYTES _BYTES);
 DEFINE_PRIM(_I32, vp8l_inverse, _I32 _BYTES _BYTES _I32 _BYTES _I32 _BYTES _I32 _I32);
 DEFINE_PRIM(_I32, alpha_unfilter, _I32 _BYTES _BYTES _I32 _BYTES _I32);
+DEFINE_PRIM(_I32, vp8l_resolve, _I32 _BYTES _BYTES _I32 _BYTES _I32);

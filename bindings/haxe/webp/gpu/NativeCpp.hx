@@ -34,5 +34,7 @@ extern class NativeCpp {
         aux:cpp.RawConstPointer<cpp.UInt8>, auxLen:cpp.SizeT, out:cpp.RawPointer<cpp.UInt8>, outLen:cpp.SizeT, swizzle:Int):Int;
     @:native("wp_alpha_unfilter") static function alphaUnfilter(n:Int, frames:cpp.RawConstPointer<cpp.Void>, src:cpp.RawConstPointer<cpp.UInt8>, srcLen:cpp.SizeT,
         alpha:cpp.RawPointer<cpp.UInt8>, alphaLen:cpp.SizeT):Int;
+    @:native("wp_vp8l_resolve") static function vp8lResolve(n:Int, frames:cpp.RawConstPointer<cpp.Void>, tokens:cpp.RawConstPointer<cpp.UInt32>, nWords:cpp.SizeT,
+        pix:cpp.RawPointer<cpp.UInt8>, pixLen:cpp.SizeT):Int;
 }
 #end
