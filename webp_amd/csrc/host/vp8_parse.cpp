@@ -44,9 +44,16 @@ struct BoolReader {
     }
 
     inline bool bit(int prob) {
-        if (nb < 8) {
-            while (nb <= 40 && p < end) { v = (v << 8) | *p++; nb += 8; }
-            if (nb < 8) { eof = true; return false; }
+        if (__builtin_expect(nb < 8, 0)) {
+            if (end - p >= 4) {                       // 4 bytes at once: nb < 8 before, so at most 39 bits afterwards
+                uint32_t w;
+                std::memcpy(&w, p, 4);
+                v = (v << 32) | __builtin_bswap32(w);
+                p += 4; nb += 32;
+            } else {
+                while (nb <= 40 && p < end) { v = (v << 8) | *p++; nb += 8; }
+                if (nb < 8) { eof = true; return false; }
+            }
         }
         const uint32_t split = ((uint32_t(range_m1) * uint32_t(prob)) >> 8) + 1;
         const int pos = nb - 8;
@@ -90,7 +97,7 @@ public:
         out_.mb.assign(size_t(nmb) * 4, 0);
         out_.filt.assign(size_t(nmb), 0);
         out_.coeff.clear();
-        out_.coeff.reserve(size_t(nmb) * 16 * 6);
+        out_.coeff.reserve(size_t(nmb) * 16 * 14);
         std::vector<uint8_t> which(size_t(nmb), 0);   // (segment << 1) | i4, resolved after the frame (Q1)
         up_.assign(size_t(out_.mbw), NzCtx());
         for (int mby = 0; mby < out_.mbh; ++mby) {
@@ -269,12 +276,17 @@ private:
     // parseResiduals4, Vp8Decoder.hx:579-637.  Writes dequantised, 16-bit-truncated values in
     // natural order into blk[16]; returns the "non-zero" context flag (first EOB test).
     // *stored: OR of the values written (0: the block is still all zero -- a product can truncate to 0).
-    int tokens(BoolReader& r, int plane, int ctx, const int* q, bool skip_first, int16_t* blk, int* stored) {
+    int tokens(BoolReader& reader, int plane, int ctx, const int* q, bool skip_first, int16_t* blk, int* stored) {
         const uint8_t (*prob)[3][11] = prob_[plane];
         *stored = 0;
         int n = skip_first ? 1 : 0;
         const uint8_t* p = prob[kBand[n]][ctx];
-        if (!r.bit(p[0])) return 0;
+        if (!reader.bit(p[0])) return 0;
+        // The decoder state works in registers from here on: through the reference its fields would be re-read and written
+        // back around every store to blk / *stored (an int* may alias them).
+        BoolReader r = reader;
+        int any = 0;
+        const int q0 = q[0], q1 = q[1];
         while (n != 16) {
             ++n;
             if (!r.bit(p[1])) { p = prob[kBand[n]][0]; continue; }
@@ -299,12 +311,15 @@ private:
                 p = prob[kBand[n]][2];
             }
             const int z = kZig[n - 1];
-            int32_t c = v * q[z > 0 ? 1 : 0];
-            if (r.bit(kUniform)) c = -c;
-            blk[z] = int16_t(uint16_t(uint32_t(c)));          // (c << 16) >> 16
-            *stored |= blk[z];
-            if (n == 16 || !r.bit(p[0])) return 1;
+            const int32_t c = v * (z > 0 ? q1 : q0);
+            const int32_t sign = -int32_t(r.bit(kUniform));       // 0 or -1: the sign is a coin flip, no branch on it
+            const int16_t w = int16_t(uint16_t(uint32_t((c ^ sign) - sign)));          // (c << 16) >> 16
+            blk[z] = w;
+            any |= w;
+            if (n == 16 || !r.bit(p[0])) break;
         }
+        reader = r;
+        *stored = any;
         return 1;
     }
 
