@@ -265,6 +265,14 @@ __global__ __launch_bounds__(kPredWaves * kWave)
 void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp,
                            const uint8_t* __restrict__ aux, uint8_t* out, int swizzle) {
     __shared__ uint32_t progress[kPredWaves];
+#ifndef WP_PRED_NO_STAGE
+    // Final pixels leave through LDS: a lane produces 32 bytes of ITS row per step, so direct stores put 64 quarter cache
+    // lines of 64 different rows into every instruction (row-strided 32-byte stores reach 1.9 TB/s, tools/ubench/row_access.hip,
+    // and the pass ran at exactly that).  Each row collects four chunks (128 bytes) here; the rows that complete a run in a
+    // step -- a quarter of them, rows are skewed by one chunk -- are written as whole 128-byte runs, eight lanes per row.
+    // Row pitch 36 dwords: the 16-byte accesses of eight consecutive lanes fall on different banks.
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kPredWaves][kPredRows][36];
+#endif
     const int wave = threadIdx.x >> 6;
     const int r = threadIdx.x & 63;                 // row within the band
     if (threadIdx.x < kPredWaves) progress[threadIdx.x] = 0;
@@ -311,7 +319,9 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
             const uint32_t* above_row = base + (long long)(y > 0 ? y - 1 : 0) * w;
             const uint8_t* tile_row = tiles + 4 * ((row_ok ? y : 0) >> bits) * tpr;
             const uint32_t* cc_row = cc_tiles + ((row_ok ? y : 0) >> cc_bits) * cc_tpr;
+#ifdef WP_PRED_NO_STAGE
             uint32_t* orow = obase + (long long)(row_ok ? y : 0) * w;
+#endif
             // the next band reads this band's last row back (unrotated, before subtract-green): that row is also stored in place
             const bool keep_raw = !to_out || (has_below && r == kPredRows - 1);
 
@@ -538,6 +548,11 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                             const uint32_t g = (res[j] >> 8) & 0xff;
                             fin[j] = swizzled(sg_out ? add_px(res[j], g | (g << 16)) : res[j], swizzle);
                         }
+#ifndef WP_PRED_NO_STAGE
+                        uint32_t* st = &stage[wave][r][(k & 3) * kPC];
+                        *reinterpret_cast<uint4*>(st) = make_uint4(fin[0], fin[1], fin[2], fin[3]);
+                        *reinterpret_cast<uint4*>(st + 4) = make_uint4(fin[4], fin[5], fin[6], fin[7]);
+#else
                         if (x0 + kPC <= w) {
 #pragma unroll
                             for (int g4 = 0; g4 < kPC / 4; ++g4) {
@@ -550,11 +565,34 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
 #pragma unroll
                             for (int j = 0; j < kPC; ++j) if (x0 + j < w) orow[x0 + j] = fin[j];
                         }
+#endif
                     }
                     TLfirst = T4[kPC - 1];
 #pragma unroll
                     for (int j = 0; j < kPC; ++j) P1[j] = res[j];
                 }
+#ifndef WP_PRED_NO_STAGE
+                if (to_out) {
+                    // rows whose chunk index is 3 mod 4 in this step have a complete 128-byte run in LDS: rows r0, r0 + 4, ...
+                    // (16 of them: two rounds of 8 rows x 8 lanes); a row that ends on another chunk index flushes what it has
+                    __builtin_amdgcn_wave_barrier();
+                    auto flush_row = [&](int rr, int piece) {
+                        const int kk = c - rr, yy = band * kPredRows + rr;
+                        if (rr < 0 || rr >= kPredRows || kk < 0 || kk >= n_chunks || yy >= h) return;
+                        const int x = (kk >> 2) * (4 * kPC) + 4 * piece;
+                        if (x >= w) return;
+                        const uint4 v = *reinterpret_cast<const uint4*>(&stage[wave][rr][4 * piece]);
+                        uint32_t* dst = obase + (long long)yy * w + x;
+                        if (x + 4 <= w) { Px4 o; o.v[0] = v.x; o.v[1] = v.y; o.v[2] = v.z; o.v[3] = v.w; *reinterpret_cast<Px4*>(dst) = o; }
+                        else { dst[0] = v.x; if (x + 1 < w) dst[1] = v.y; if (x + 2 < w) dst[2] = v.z; }
+                    };
+                    const int r0 = (c + 1) & 3;
+#pragma unroll
+                    for (int round = 0; round < 2; ++round) flush_row(r0 + 4 * ((r >> 3) + 8 * round), r & 7);
+                    if (((n_chunks - 1) & 3) != 3 && r < 8) flush_row(c - (n_chunks - 1), r);
+                    __builtin_amdgcn_wave_barrier();
+                }
+#endif
                 if (has_below) {
                     // What is announced is the count reached two steps ago: its stores have had two steps to land, so the
                     // release fence (s_waitcnt vmcnt(0)) does not stall the band on the stores it has only just issued.
