@@ -260,6 +260,13 @@ constexpr int kPredWaves = WP_PRED_WAVES;
 #define WP_PRED_CHUNK 8
 #endif
 constexpr int kPC = WP_PRED_CHUNK;
+// A band tells the one below how far its last row has got every kPredPublishPx pixels.  Publishing is a release fence, and
+// on gfx9 that is s_waitcnt vmcnt(0): the wavefront drains ALL its memory operations, the loads it has just issued for the
+// next step included -- a full trip to memory on the band's critical path every time.
+#ifndef WP_PRED_PUBLISH_PX
+#define WP_PRED_PUBLISH_PX 16
+#endif
+constexpr int kPredPublishPx = WP_PRED_PUBLISH_PX;
 
 __global__ __launch_bounds__(kPredWaves * kWave)
 void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp,
@@ -597,7 +604,7 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                     // What is announced is the count reached two steps ago: its stores have had two steps to land, so the
                     // release fence (s_waitcnt vmcnt(0)) does not stall the band on the stores it has only just issued.
                     const int k_last = c - (kPredRows - 1);
-                    if (k_last >= 0 && (((k_last + 1) * kPC) % 16 == 0 || k_last == n_chunks - 1)) {
+                    if (k_last >= 0 && (((k_last + 1) * kPC) % kPredPublishPx == 0 || k_last == n_chunks - 1)) {
                         if (pending_publish) publish_progress(&progress[wave], pending_publish);
                         pending_publish = (q << kPredSeqShift) | uint32_t(min(kPC * (k_last + 1), w));
                     }
