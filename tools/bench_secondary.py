@@ -133,7 +133,7 @@ def anim_alpha(device, n=300, reps=4):
                    % (n, frames[0].alpha_filter), ms, px, alg, len(idx), host_parse_s=round(t_parse, 3), file_bytes=len(anim))
 
 
-def lossy_4k(device, n=1024, steps=5):
+def lossy_4k(device, n=1024, steps=16):
     import numpy as np
     import torch
     import bench
