@@ -44,6 +44,11 @@ HL_PRIM int HL_NAME(vp8l_resolve)(int n, vbyte* frames, vbyte* tokens, int n_wor
     return wp_vp8l_resolve(n, (const wp_vp8l_tokens_frame*)frames, (const uint32_t*)tokens, (size_t)n_words, pix, (size_t)pix_len);
 }
 
+/* canvas compositing (not in the reference, which composes nothing): wp_anim_frame = 32 bytes */
+HL_PRIM int HL_NAME(anim_compose)(int n, vbyte* frames, int canvas_w, int canvas_h, vbyte* argb, int argb_len, vbyte* canvases, int canvases_len) {
+    return wp_anim_compose(n, (const wp_anim_frame*)frames, canvas_w, canvas_h, argb, (size_t)argb_len, canvases, (size_t)canvases_len);
+}
+
 DEFINE_PRIM(_I32, init, _I32);
 DEFINE_PRIM(_I32, shutdown, _NO_ARG);
 DEFINE_PRIM(_I32, device_count, _NO_ARG);
@@ -55,3 +60,4 @@ DEFINE_PRIM(_I32, yuv420_to_argb, _I32 _BYTES _BYTES _BYTES _BYTES _BYTES _BYTES
 DEFINE_PRIM(_I32, vp8l_inverse, _I32 _BYTES _BYTES _I32 _BYTES _I32 _BYTES _I32 _I32);
 DEFINE_PRIM(_I32, alpha_unfilter, _I32 _BYTES _BYTES _I32 _BYTES _I32);
 DEFINE_PRIM(_I32, vp8l_resolve, _I32 _BYTES _BYTES _I32 _BYTES _I32);
+DEFINE_PRIM(_I32, anim_compose, _I32 _BYTES _I32 _I32 _BYTES _I32 _BYTES _I32);

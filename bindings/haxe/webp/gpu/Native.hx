@@ -19,5 +19,6 @@ extern class Native {
     static function vp8l_inverse(n:Int, frames:hl.Bytes, pix:hl.Bytes, pixLen:Int, aux:hl.Bytes, auxLen:Int, out:hl.Bytes, outLen:Int, swizzle:Int):Int;
     static function alpha_unfilter(n:Int, frames:hl.Bytes, src:hl.Bytes, srcLen:Int, alpha:hl.Bytes, alphaLen:Int):Int;
     static function vp8l_resolve(n:Int, frames:hl.Bytes, tokens:hl.Bytes, nWords:Int, pix:hl.Bytes, pixLen:Int):Int;
+    static function anim_compose(n:Int, frames:hl.Bytes, canvasW:Int, canvasH:Int, argb:hl.Bytes, argbLen:Int, canvases:hl.Bytes, canvasesLen:Int):Int;
 }
 #end

@@ -36,5 +36,7 @@ extern class NativeCpp {
         alpha:cpp.RawPointer<cpp.UInt8>, alphaLen:cpp.SizeT):Int;
     @:native("wp_vp8l_resolve") static function vp8lResolve(n:Int, frames:cpp.RawConstPointer<cpp.Void>, tokens:cpp.RawConstPointer<cpp.UInt32>, nWords:cpp.SizeT,
         pix:cpp.RawPointer<cpp.UInt8>, pixLen:cpp.SizeT):Int;
+    @:native("wp_anim_compose") static function animCompose(n:Int, frames:cpp.RawConstPointer<cpp.Void>, canvasW:Int, canvasH:Int,
+        argb:cpp.RawConstPointer<cpp.UInt8>, argbLen:cpp.SizeT, canvases:cpp.RawPointer<cpp.UInt8>, canvasesLen:cpp.SizeT):Int;
 }
 #end

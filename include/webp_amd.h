@@ -132,6 +132,18 @@ typedef struct wp_alpha_frame {
     uint64_t dst_off;           /* byte offset in the alpha slab */
 } wp_alpha_frame;
 
+/* One frame of an animation for canvas compositing.  The reference stops at independent frames
+ * (Image.hx:21-34 AnimFrameHeader, WebPDecoder.hx:150-177 readAnmf: x, y, width, height, duration, blend, dispose are
+ * parsed and handed to the caller, nothing is composed); the rules applied here are the WebP container specification's
+ * ("Assembling the Canvas from Frames") in the integer arithmetic of libwebp's WebPAnimDecoder, non-premultiplied. */
+typedef struct wp_anim_frame {
+    int32_t x, y;               /* AnimFrameHeader.x / .y as stored in the file: units of 2 pixels (offset = 2x, 2y) */
+    int32_t width, height;      /* AnimFrameHeader.width / .height */
+    int32_t blend;              /* AnimFrameHeader.blend: 1 = alpha-blend over the canvas, 0 = overwrite the rectangle */
+    int32_t dispose;            /* AnimFrameHeader.dispose: 1 = clear the rectangle to transparent before the NEXT frame */
+    uint64_t argb_off;          /* byte offset of the frame's pixels (A,R,G,B, tight stride 4*width) in the frame slab */
+} wp_anim_frame;
+
 /* ------------------------------------------------------------------------------------------ */
 /* Lifecycle                                                                                    */
 /* ------------------------------------------------------------------------------------------ */
@@ -262,6 +274,13 @@ int wp_vp8l_resolve_dev(int n, const wp_vp8l_tokens_frame* frames_host, const wp
  * ("Invalid LZ77 parameters", "Invalid color cache index", "null color cache") or a note on what is malformed. */
 int wp_vp8l_check_tokens(const wp_vp8l_tokens_frame* frame, const uint32_t* tokens /* the frame's stream, host memory */);
 
+/* Canvas compositing of one animation: canvas k (k = 0..n-1, each 4*canvas_w*canvas_h bytes, A,R,G,B, laid one after the
+ * other in d_canvases) is what a viewer shows after frame k.  No counterpart in the reference (see wp_anim_frame).  Frame
+ * rectangles are clipped to the canvas; the background is transparent black (the ANIM chunk's colour is ignored, as
+ * libwebp's decoder does). */
+int wp_anim_compose_dev(int n, const wp_anim_frame* frames_host, const wp_anim_frame* d_frames, int canvas_w, int canvas_h,
+                        const uint8_t* d_argb, uint8_t* d_canvases, void* stream);
+
 /* Alpha plane: optional green-channel extraction + unfilterAlpha (WebPDecoder.hx:311-411). */
 int wp_alpha_unfilter_dev(int n, const wp_alpha_frame* frames_host, const wp_alpha_frame* d_frames,
                           const uint8_t* d_src, uint8_t* d_alpha, void* stream);
@@ -291,6 +310,8 @@ int wp_vp8l_inverse(int n, const wp_vp8l_frame* frames, const uint8_t* pix, size
                     const uint8_t* aux, size_t aux_len, uint8_t* out, size_t out_len, int swizzle);
 int wp_alpha_unfilter(int n, const wp_alpha_frame* frames, const uint8_t* src, size_t src_len,
                       uint8_t* alpha, size_t alpha_len);
+int wp_anim_compose(int n, const wp_anim_frame* frames, int canvas_w, int canvas_h, const uint8_t* argb, size_t argb_len,
+                    uint8_t* canvases, size_t canvases_len);
 /* wp_vp8l_resolve_dev on host memory; every stream is checked (wp_vp8l_check_tokens) before anything is uploaded. */
 int wp_vp8l_resolve(int n, const wp_vp8l_tokens_frame* frames, const uint32_t* tokens, size_t n_words,
                     uint8_t* pix, size_t pix_len);

@@ -117,3 +117,18 @@ def resolve_tokens(w, h, cc_bits, tokens):
     if rc:
         raise OracleError(L.wo_last_error().decode())
     return pix
+
+def anim_compose(frames, canvas_w, canvas_h):
+    """Canvas compositing (WebP container spec, libwebp WebPAnimDecoder arithmetic): frames = [(x, y, width, height, blend,
+    dispose, argb_bytes)], x / y in the file's units of 2 pixels; returns uint8 [n, canvas_h, canvas_w, 4] (A,R,G,B)."""
+    n = len(frames)
+    desc = np.array([[f[0], f[1], f[2], f[3], int(f[4]), int(f[5])] for f in frames], np.int32).reshape(-1)
+    bufs = [np.ascontiguousarray(f[6], dtype=np.uint8) for f in frames]
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+    out = np.zeros((n, canvas_h, canvas_w, 4), np.uint8)
+    L = lib()
+    L.wo_anim_compose.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    rc = L.wo_anim_compose(n, _p(desc), canvas_w, canvas_h, ptrs, _p(out))
+    if rc:
+        raise OracleError(L.wo_last_error().decode())
+    return out

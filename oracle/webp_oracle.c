@@ -1866,3 +1866,58 @@ int wo_info(const wo_image* im, int which) {
                      case 7: return im->fx; case 8: return im->fy; case 9: return im->duration; case 10: return im->blend; case 11: return im->dispose; }
     return 0;
 }
+
+/* ---- Canvas compositing.  The reference parses AnimFrameHeader (Image.hx:21-34, WebPDecoder.hx:150-177)
+ * and does no compositing, so this follows the WebP container specification ("Assembling the Canvas from Frames") in the
+ * integer arithmetic of libwebp's WebPAnimDecoder (src/demux/anim_decode.c: IsKeyFrame, ZeroFillFrameRect,
+ * BlendPixelNonPremult, FindBlendRangeAtRow), restated frame by frame on a whole canvas the way that decoder works.
+ * Pinned by tests/golden/anim/ (canvases produced by that decoder through PIL).  Pixels: A,R,G,B bytes.
+ * frames: n x {x, y, width, height, blend, dispose} (x, y in units of 2 pixels); pix[k]: frame k's pixels, tight. */
+static uint32_t wo_blend_non_premult(const uint8_t* s, const uint8_t* d) {        /* returns A | R<<8 | G<<16 | B<<24 */
+    uint32_t src_a = s[0], dst_a = d[0];
+    uint32_t dst_factor_a = (dst_a * (256 - src_a)) >> 8;
+    uint32_t blend_a = src_a + dst_factor_a;
+    uint32_t scale = (1u << 24) / blend_a;
+    uint32_t out = blend_a;
+    for (int c = 1; c < 4; c++) out |= (((uint32_t)s[c] * src_a + (uint32_t)d[c] * dst_factor_a) * scale >> 24) << (8 * c);
+    return out;
+}
+int wo_anim_compose(int n, const int32_t* frames, int cw, int ch, const uint8_t* const* pix, uint8_t* canvases) {
+    size_t csz = (size_t)4 * cw * ch;
+    uint8_t* prev = (uint8_t*)calloc(csz ? csz : 1, 1);         /* previous canvas with the previous frame's disposal applied */
+    if (!prev) return fail(WO_ERR_ALLOC, "alloc");
+    int prev_key = 0, prev_full = 0, prev_dispose = 0, px0 = 0, py0 = 0, pw = 0, ph = 0;
+    for (int k = 0; k < n; k++) {
+        const int32_t* f = frames + 6 * k;
+        int x0 = 2 * f[0], y0 = 2 * f[1], w = f[2], h = f[3], blend = f[4], dispose = f[5];
+        int full = x0 == 0 && y0 == 0 && w == cw && h == ch;
+        int key = k == 0 || (!blend && full) || (prev_dispose && (prev_full || prev_key));
+        uint8_t* cur = canvases + (size_t)k * csz;
+        if (key) memset(prev, 0, csz);
+        else if (prev_dispose)
+            for (int y = py0; y < py0 + ph && y < ch; y++)
+                for (int x = px0; x < px0 + pw && x < cw; x++) memset(prev + 4 * ((size_t)y * cw + x), 0, 4);
+        memcpy(cur, prev, csz);
+        for (int y = 0; y < h; y++) {
+            int cy = y0 + y;
+            if (cy >= ch) break;
+            for (int x = 0; x < w; x++) {
+                int cx = x0 + x;
+                if (cx >= cw) break;
+                const uint8_t* s = pix[k] + 4 * ((size_t)y * w + x);
+                uint8_t* d = cur + 4 * ((size_t)cy * cw + cx);
+                int in_prev_rect = prev_dispose && cx >= px0 && cx < px0 + pw && cy >= py0 && cy < py0 + ph;
+                if (blend && !key && !in_prev_rect && s[0] != 0xff) {
+                    if (s[0] != 0) { uint32_t v = wo_blend_non_premult(s, d); d[0] = v & 0xff; d[1] = (v >> 8) & 0xff; d[2] = (v >> 16) & 0xff; d[3] = v >> 24; }
+                    /* alpha 0: the canvas pixel stays */
+                } else {
+                    memcpy(d, s, 4);
+                }
+            }
+        }
+        memcpy(prev, cur, csz);
+        prev_key = key; prev_full = full; prev_dispose = dispose != 0; px0 = x0; py0 = y0; pw = w; ph = h;
+    }
+    free(prev);
+    return 0;
+}

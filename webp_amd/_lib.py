@@ -39,6 +39,11 @@ class Vp8lTokensFrame(ctypes.Structure):   # wp_vp8l_tokens_frame
                 ("tok_off", ctypes.c_uint64), ("n_words", ctypes.c_uint64), ("pix_off", ctypes.c_uint64)]
 
 
+class AnimFrame(ctypes.Structure):         # wp_anim_frame
+    _fields_ = [("x", ctypes.c_int32), ("y", ctypes.c_int32), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("blend", ctypes.c_int32), ("dispose", ctypes.c_int32), ("argb_off", ctypes.c_uint64)]
+
+
 class Vp8BatchSizes(ctypes.Structure):   # wp_vp8_batch_sizes
     _fields_ = [(k, ctypes.c_uint64) for k in ("n_mb", "n_coeff_blocks", "y_bytes", "u_bytes", "v_bytes", "argb_bytes",
                                                "alpha_bytes", "work_bytes")]
@@ -92,6 +97,8 @@ def lib():
     L.wp_vp8_loopfilter.argtypes = [i32, vp, vp, sz, vp, vp, vp]
     L.wp_vp8l_inverse.argtypes = [i32, vp, vp, sz, vp, sz, vp, sz, i32]
     L.wp_alpha_unfilter.argtypes = [i32, vp, vp, sz, vp, sz]
+    L.wp_anim_compose_dev.argtypes = [i32, vp, vp, i32, i32, vp, vp, vp]
+    L.wp_anim_compose.argtypes = [i32, vp, i32, i32, vp, sz, vp, sz]
     L.wp_vp8l_resolve_dev.argtypes = [i32, vp, vp, vp, vp, vp]
     L.wp_vp8l_check_tokens.argtypes = [vp, vp]
     L.wp_vp8l_resolve.argtypes = [i32, vp, vp, sz, vp, sz]

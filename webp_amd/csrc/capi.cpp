@@ -30,6 +30,7 @@ int wpk_launch_yuv420_to_argb(int n, int grid_x, const wp_vp8_frame* d_frames, c
                               const uint8_t* d_v, const uint8_t* d_alpha, uint8_t* d_argb, hipStream_t stream);
 int wpk_launch_vp8l(int n, const wp_vp8l_frame* frames_host, const wp_vp8l_frame* d_frames, uint8_t* d_pix, const uint8_t* d_aux,
                     uint8_t* d_tmp, uint8_t* d_out, int swizzle, hipStream_t stream);
+int wpk_launch_anim_compose(int n, const wp_anim_frame* d_frames, int cw, int ch, const uint8_t* d_argb, uint8_t* d_canvases, hipStream_t stream);
 int wpk_launch_vp8l_resolve(int n, const wp_vp8l_tokens_frame* d_frames, const uint32_t* d_tokens, uint8_t* d_pix, hipStream_t stream);
 int wpk_launch_alpha(int n, const wp_alpha_frame* frames_host, const wp_alpha_frame* d_frames, const uint8_t* d_src, uint8_t* d_alpha,
                      hipStream_t stream);
@@ -441,6 +442,24 @@ int wp_vp8l_inverse_dev(int n, const wp_vp8l_frame* fh, const wp_vp8l_frame* fd,
     return WP_OK;
 }
 
+static int bad_anim_args(int n, const wp_anim_frame* f, int cw, int ch) {
+    if (n < 0 || (n > 0 && !f) || cw <= 0 || ch <= 0 || cw > (1 << 24) || ch > (1 << 24)) return 1;      // 24-bit canvas size (VP8X)
+    for (int i = 0; i < n; ++i)
+        if (f[i].x < 0 || f[i].y < 0 || f[i].x >= (1 << 24) || f[i].y >= (1 << 24) || f[i].width <= 0 || f[i].height <= 0 ||
+            f[i].width > (1 << 24) || f[i].height > (1 << 24) || (f[i].argb_off & 3)) return 1;
+    return 0;
+}
+
+int wp_anim_compose_dev(int n, const wp_anim_frame* fh, const wp_anim_frame* fd, int canvas_w, int canvas_h, const uint8_t* d_argb,
+                        uint8_t* d_canvases, void* stream) {
+    int rc = ensure_init(); if (rc) return rc;
+    if (bad_anim_args(n, fh, canvas_w, canvas_h) || (n > 0 && (!fd || !d_argb || !d_canvases))) return fail(WP_ERR_INVALID, "bad argument");
+    if (n == 0) return WP_OK;
+    const int e = wpk_launch_anim_compose(n, fd, canvas_w, canvas_h, d_argb, d_canvases, hipStream_t(stream));
+    if (e) return hip_fail(hipError_t(e), "anim compose launch");
+    return WP_OK;
+}
+
 static int bad_tokens_frame(const wp_vp8l_tokens_frame& a) {
     return a.coded_width <= 0 || a.height <= 0 || a.coded_width > 16384 || a.height > 16384 || a.cc_bits < 0 || a.cc_bits > 11 ||
            (a.tok_off & 3) || (a.pix_off & 15) || a.n_words >= (uint64_t(1) << 32) - 256;
@@ -703,6 +722,26 @@ int wp_vp8l_inverse(int n, const wp_vp8l_frame* frames, const uint8_t* pix, size
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout.p, out_len, hipMemcpyDeviceToHost));
+    return WP_OK;
+}
+
+int wp_anim_compose(int n, const wp_anim_frame* frames, int canvas_w, int canvas_h, const uint8_t* argb, size_t argb_len,
+                    uint8_t* canvases, size_t canvases_len) {
+    int rc = ensure_init(); if (rc) return rc;
+    if (bad_anim_args(n, frames, canvas_w, canvas_h) || (n > 0 && (!argb || !canvases))) return fail(WP_ERR_INVALID, "bad argument");
+    if (n == 0) return WP_OK;
+    auto fits = [](uint64_t off, uint64_t extent, uint64_t len) { return off <= len && extent <= len - off; };
+    for (int i = 0; i < n; ++i)
+        if (!fits(frames[i].argb_off, uint64_t(4) * uint64_t(frames[i].width) * uint64_t(frames[i].height), argb_len))
+            return fail(WP_ERR_INVALID, "frame slab too small");
+    const uint64_t need = uint64_t(4) * uint64_t(canvas_w) * uint64_t(canvas_h) * uint64_t(n);
+    if (need > canvases_len) return fail(WP_ERR_INVALID, "canvas slab too small");
+    DevBuf dfr, dsrc, dout;
+    if ((rc = dfr.upload(frames, sizeof(wp_anim_frame) * size_t(n))) || (rc = dsrc.upload(argb, argb_len)) || (rc = dout.alloc(size_t(need)))) return rc;
+    rc = wp_anim_compose_dev(n, frames, dfr.as<wp_anim_frame>(), canvas_w, canvas_h, dsrc.as<uint8_t>(), dout.as<uint8_t>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(canvases, dout.p, size_t(need), hipMemcpyDeviceToHost));
     return WP_OK;
 }
 

@@ -522,6 +522,28 @@ class Tools:
         return Image(hdr, Argb(pix, 4 * w))
 
     @staticmethod
+    def composeAnim(img: Image) -> List[np.ndarray]:
+        """What a viewer shows after each frame of an animation: one canvas (header.width x header.height, A,R,G,B) per frame.
+        Not in the reference, which hands AnimFrameHeader to the caller and composes nothing (Image.hx:21-34; SURVEY 8f item
+        4); the rules are the WebP container specification's in libwebp's arithmetic (wp_anim_compose).  A still yields its
+        one frame."""
+        frames = Tools.framesToArgb(img)
+        if not isinstance(img.data, Anim):
+            return frames
+        n = len(frames)
+        cw, ch = img.header.width, img.header.height
+        desc = (_lib.AnimFrame * max(n, 1))()
+        off = 0
+        for k, f in enumerate(img.data.frames):
+            d, h = desc[k], f.header
+            d.x, d.y, d.width, d.height, d.blend, d.dispose, d.argb_off = h.x, h.y, h.width, h.height, int(h.blend), int(h.dispose), off
+            off += frames[k].size
+        slab = np.concatenate(frames) if n else np.zeros(4, np.uint8)
+        out = np.empty(n * 4 * cw * ch, np.uint8)
+        check(lib().wp_anim_compose(n, desc, cw, ch, _np_ptr(slab), slab.size, _np_ptr(out), out.size))
+        return [out[k * 4 * cw * ch:(k + 1) * 4 * cw * ch] for k in range(n)]
+
+    @staticmethod
     def framesToArgb(img: Image) -> List[np.ndarray]:
         """Per-frame conversion as test/Visual.hx:32-40, 45-89 does: tightly packed ARGB per frame."""
         if isinstance(img.data, Anim):
