@@ -129,8 +129,57 @@ def anim_alpha(device, n=300, reps=4):
             raise RuntimeError("planes of frame %d of the animation differ from the oracle" % i)
     px = sum(batch.desc[i].width * batch.desc[i].height for i in range(n))
     alg = batch.input_bytes() + 384 * batch.n_mb + 4 * px + px + lb.pix.size + lb.aux.size        # + alpha plane read, + the coded alpha image
+    # canvas compositing of the same animation on the device: frames are where the finishing pass left them
+    from webp_amd._lib import AnimFrame
+    cdesc = (AnimFrame * n)()
+    for i, f in enumerate(frames):
+        c = cdesc[i]
+        c.x, c.y, c.width, c.height, c.blend, c.dispose, c.argb_off = f.x, f.y, f.width, f.height, int(f.blend), int(f.dispose), batch.desc[i].argb_off
+    d_cf = torch.from_numpy(np.frombuffer(bytes(cdesc), dtype=np.uint8).copy()).to(device)
+    canvases = torch.empty(n * 4 * pf.width * pf.height, dtype=torch.uint8, device=device)
+    compose = lambda: check(lib().wp_anim_compose_dev(n, cdesc, d_cf.data_ptr(), pf.width, pf.height, db.argb.data_ptr(), canvases.data_ptr(), stream))
+    compose_ms = _timed(compose, reps)
+    k_chk = 4
+    want_c = oracle.anim_compose([(w["x"], w["y_off"], w["width"], w["height"], w["blend"], w["dispose"], w["to_argb"]) for w in want[:k_chk]], pf.width, pf.height)
+    got_c = canvases[:k_chk * 4 * pf.width * pf.height].cpu().numpy().reshape(want_c.shape)
+    if not np.array_equal(got_c, want_c):
+        raise RuntimeError("composed canvases of the animation differ from the oracle")
+    compose_bytes = 4 * px + 4 * n * pf.width * pf.height
+    extra_compose = {"compose_ms": round(compose_ms, 4), "compose_Mpix_s": round(n * pf.width * pf.height / compose_ms / 1e3, 1),
+                     "compose_frac": round(compose_bytes / (compose_ms * 1e-3) / 8e12, 4), "compose_verified_canvases": k_chk}
     return _record("cfg4_anim_720p_alpha", "one animated WebP (ANMF), %d frames of 1280x720 lossy + VP8L-coded ALPH (filter %d): alpha chain + unfilterAlpha + recon + loop filter + finishing pass with alpha"
-                   % (n, frames[0].alpha_filter), ms, px, alg, len(idx), host_parse_s=round(t_parse, 3), file_bytes=len(anim))
+                   % (n, frames[0].alpha_filter), ms, px, alg, len(idx), host_parse_s=round(t_parse, 3), file_bytes=len(anim), **extra_compose)
+
+
+def vp8l_resolve(device, n=512):
+    """decodePix's pixel loop on the device (first slice): n copies of a photo-like lossless stream's tokens."""
+    import numpy as np
+    import torch
+    from oracle import oracle
+    from webp_amd import parse
+    from webp_amd._lib import Vp8lTokensFrame, check, lib
+    path = os.path.join(ROOT, "tests", "golden", "inputs", "3ll.webp")
+    f = parse(open(path, "rb").read(), vp8l_tokens=True).frames[0]
+    tk = f.buf(6, np.uint32)
+    w, h = f.coded_width, f.vp8l_height
+    stride = (4 * w * h + 255) // 256 * 256
+    desc = (Vp8lTokensFrame * n)()
+    for i in range(n):
+        d = desc[i]
+        d.coded_width, d.height, d.cc_bits, d.tok_off, d.n_words, d.pix_off = w, h, f.cc_bits, 0, tk.size, stride * i
+    tok = torch.from_numpy(tk.view(np.int32).copy()).to(device)
+    dd = torch.from_numpy(np.frombuffer(bytes(desc), np.uint8).copy()).to(device)
+    pix = torch.empty(stride * n, dtype=torch.uint8, device=device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    ms = _timed(lambda: check(lib().wp_vp8l_resolve_dev(n, desc, dd.data_ptr(), tok.data_ptr(), pix.data_ptr(), stream)), 3)
+    want = oracle.resolve_tokens(w, h, f.cc_bits, tk)
+    idx = [0, n // 2, n - 1]
+    for i in idx:
+        if not np.array_equal(pix[stride * i:stride * i + 4 * w * h].cpu().numpy(), want):
+            raise RuntimeError("resolved pixels of image %d differ from the oracle" % i)
+    return _record("f2_vp8l_pixel_loop", "%d x %dx%d VP8L token streams (photo-like, %d tokens words each, colour cache of %d entries): literal runs + LZ77 copies + "
+                   "colour-cache fill / lookup (Vp8LDecoder.hx:283-333) on the device, one wavefront per image" % (n, w, h, tk.size, 1 << f.cc_bits),
+                   ms, n * w * h, n * (4 * tk.size + 4 * w * h), len(idx), note="latency-bound per token; the host's Huffman decode still precedes it")
 
 
 def lossy_4k(device, n=1024, steps=16):
@@ -195,7 +244,7 @@ def run_all(device):
     import gc
     import torch
     out = []
-    for fn in (lossless, anim_alpha, lossy_4k, end_to_end):
+    for fn in (lossless, anim_alpha, lossy_4k, vp8l_resolve, end_to_end):
         t0 = time.time()
         try:
             rec = fn(device)
