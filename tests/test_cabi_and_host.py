@@ -295,3 +295,29 @@ def test_plan_schedules_heavy_frames_with_light_ones():
     # within every round of `grid` slots the costs are monotonic; with no GPU (grid unknown -> 2 per CU of 0 CUs -> 1) or a
     # grid larger than the batch this is one descending run
     assert costs[0] == max(costs)
+
+
+def test_anmf_header_larger_than_the_vp8_stream_does_not_fail_the_batch():
+    """An ANMF frame whose header claims a larger size than its VP8 stream decodes with the stream's size (the reference sizes
+    the planes from the VP8 header, Vp8Decoder.ensureImg) instead of making wp_vp8_batch_layout refuse the whole batch."""
+    import glob
+    import struct
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_anim import build_anim
+    from webp_amd.decoder import LossyBatch, parse
+    stills = sorted(glob.glob(os.path.join(ROOT, "bench_data", "lossy720_alpha_*.webp")))
+    if not stills:
+        pytest.skip("bench_data/lossy720_alpha_*.webp missing")
+    data = bytearray(build_anim([open(p, "rb").read() for p in stills], 2))
+    pos = 12
+    while pos + 8 <= len(data):
+        tag, n = bytes(data[pos:pos + 4]), struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        if tag == b"ANMF":
+            data[pos + 8 + 6:pos + 8 + 9] = (4000 - 1).to_bytes(3, "little")        # frame width minus one: far beyond the stream's 1280
+            break
+        pos += 8 + n + (n & 1)
+    pf = parse(bytes(data))
+    assert pf.frames[0].width == 4000
+    b = LossyBatch(pf.frames)
+    assert (b.desc[0].width, b.desc[0].height) == (1280, 720) and (b.desc[1].width, b.desc[1].height) == (1280, 720)

@@ -980,7 +980,12 @@ int wp_vp8_batch_layout(int n, const wp_parsed* const* files, const int* frame_i
         if (z.n_mb + nmb > 0xffffffffull || st > 0xffffffffull) return fail(WP_ERR_INVALID, "batch too large for 32-bit record indices");
         wp_vp8_frame& d = frames[i];
         d = wp_vp8_frame{};
-        d.width = f->width; d.height = f->height; d.mbw = f->vp8.mbw; d.mbh = f->vp8.mbh;
+        d.mbw = f->vp8.mbw; d.mbh = f->vp8.mbh;
+        // Visible size: the frame's own (ANMF header for animation frames, as test/Visual.hx uses it).  An ANMF header that
+        // claims more than the VP8 stream's planes hold cannot be honoured: the reference builds the planes from the VP8
+        // header (Vp8Decoder.ensureImg) and so does this frame -- alone, instead of failing the whole batch.
+        d.width = (f->width > 0 && f->width <= 16 * d.mbw) ? f->width : f->vp8.width;
+        d.height = (f->height > 0 && f->height <= 16 * d.mbh) ? f->height : f->vp8.height;
         d.filter_type = f->vp8.filter_type;
         d.has_alpha = (with_alpha && with_alpha[i]) ? 1 : 0;
         d.mb_base = uint32_t(z.n_mb); d.stile_base = uint32_t(st); d.coeff_base = z.n_coeff_blocks;
