@@ -12,15 +12,51 @@
 
 namespace wpk {
 
+#ifndef WP_FINISH_PER_WG
+#define WP_FINISH_PER_WG 1
+#endif
+constexpr int kFinishPerWg = WP_FINISH_PER_WG;
+
 __global__ __launch_bounds__(256)
 void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* __restrict__ Rp, const uint8_t* __restrict__ Sp,
                        int force_unshifted, uint8_t* Yp, uint8_t* Up, uint8_t* Vp, const uint8_t* __restrict__ Ap, uint8_t* out) {
     __shared__ uint4 tiles4[kFinishLdsBytes / 16];
     const wp_vp8_frame& fr = frames[blockIdx.z];
     const bool shifted = !force_unshifted;
-    const int ty = blockIdx.y, c0 = blockIdx.x * kFinishCols;     // output columns c0 .. c0+255
-    if (ty >= fr.mbh + (shifted ? 1 : 0) || c0 >= 16 * fr.mbw) return;
-    finish_chunk(fr, ty, c0, int(threadIdx.x), tiles4, Rp, Sp, shifted, Yp, Up, Vp, Ap, out);
+    const int t = int(threadIdx.x);
+    const int ty = blockIdx.y, c_first = blockIdx.x * (kFinishPerWg * kFinishCols);
+    const int c_end = 16 * fr.mbw;
+    if (ty >= fr.mbh + (shifted ? 1 : 0) || c_first >= c_end) return;
+    // kFinishPerWg adjacent chunks per workgroup, the next chunk's tiles fetched into registers while the current one is
+    // converted.  Built to test whether the pass, of which a CU holds only two workgroups beside the one-kernel
+    // reconstruction + loop filter, is bound there by the latency of its one load per workgroup: it is not -- with 2, 3, 4 or
+    // 8 chunks per workgroup (32 registers, same residency) a pipelined step takes 7.07 / 7.04 / 7.10 / 6.94 ms against 7.10
+    // with one, and the pass alone 2.93 - 3.14 ms against 2.84.  Default 1.
+    FinishSrc fs = finish_src(fr, ty, c_first, Rp, Sp, shifted);
+    u32x4 nx = finish_fetch(fs, t);
+    int nx_nt = fs.nt;
+#pragma unroll
+    for (int i = 0; i < kFinishPerWg; ++i) {
+        const int c0 = c_first + i * kFinishCols;
+        if (c0 >= c_end) break;
+        if (i) __syncthreads();                               // the chunk before has been read out of LDS
+        const int nt = nx_nt;
+        // everything derived from the thread index is re-derived per chunk from an opaque copy: shared across the unrolled
+        // chunks it would sit in registers for the whole kernel, and 32 registers is the budget (two waves per SIMD beside
+        // vp8_mb_kernel)
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        if (tt < nt * (kTileBytes / 16)) tiles4[tt] = make_uint4(nx.x, nx.y, nx.z, nx.w);
+        __syncthreads();
+        if (i + 1 < kFinishPerWg && c0 + kFinishCols < c_end) {
+            fs = finish_src(fr, ty, c0 + kFinishCols, Rp, Sp, shifted);
+            nx = finish_fetch(fs, tt);
+            nx_nt = fs.nt;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        finish_emit(fr, ty, c0, tt, nt, tiles4, shifted, Yp, Up, Vp, Ap, out);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // Row-major planes -> R tiles (only used by the stand-alone loop-filter entry point).
@@ -48,7 +84,7 @@ void vp8_tile_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* __r
 extern "C" int wpk_launch_vp8_finish(int n, int chunks, int tile_rows, const wp_vp8_frame* d_frames, const uint8_t* d_rtiles,
                                      const uint8_t* d_stiles, int force_unshifted, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
                                      const uint8_t* d_alpha, uint8_t* d_argb, hipStream_t stream) {
-    hipLaunchKernelGGL(wpk::vp8_finish_kernel, dim3(chunks, tile_rows, n), dim3(256), 0, stream,
+    hipLaunchKernelGGL(wpk::vp8_finish_kernel, dim3((chunks + wpk::kFinishPerWg - 1) / wpk::kFinishPerWg, tile_rows, n), dim3(256), 0, stream,
                        d_frames, d_rtiles, d_stiles, force_unshifted, d_y, d_u, d_v, d_alpha, d_argb);
     return int(hipGetLastError());
 }

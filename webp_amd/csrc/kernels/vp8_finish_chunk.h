@@ -25,19 +25,29 @@ constexpr int kFinishCols = 128;                       // output luma columns pe
 constexpr int kFinishTiles = kFinishCols / 16 + 1;      // source tiles that can overlap them
 constexpr int kFinishLdsBytes = kFinishTiles * kTileBytes;
 
-// t: thread index in the workgroup of 256 (8 row pairs x 32 pixel quads); tiles4: kFinishLdsBytes of LDS.
-__device__ __forceinline__ void finish_chunk(const wp_vp8_frame& fr, int ty, int c0, int t, uint4* tiles4,
-                                             const uint8_t* __restrict__ Rp, const uint8_t* __restrict__ Sp, bool shifted,
-                                             uint8_t* Yp, uint8_t* Up, uint8_t* Vp, const uint8_t* __restrict__ Ap, uint8_t* out) {
+// What a chunk reads: up to kFinishTiles source tiles, contiguous in memory.
+struct FinishSrc { const uint8_t* src; int nt; };
+__device__ __forceinline__ FinishSrc finish_src(const wp_vp8_frame& fr, int ty, int c0, const uint8_t* __restrict__ Rp, const uint8_t* __restrict__ Sp, bool shifted) {
+    const int ntx = fr.mbw + (shifted ? 1 : 0);
+    const int tx0 = c0 >> 4;                                      // (c0 + shift) >> 4: first source tile
+    FinishSrc r;
+    r.nt = min(shifted ? kFinishTiles : kFinishTiles - 1, ntx - tx0);
+    r.src = (shifted ? Sp + size_t(fr.stile_base) * kTileBytes : Rp + size_t(fr.mb_base) * kTileBytes) + (size_t(ty) * ntx + tx0) * kTileBytes;
+    return r;
+}
+// thread t's 16 bytes of the chunk's source tiles (zeros beyond them)
+__device__ __forceinline__ u32x4 finish_fetch(const FinishSrc& fs, int t) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (t < fs.nt * (kTileBytes / 16)) v = WP_NT_LOAD(reinterpret_cast<const u32x4*>(fs.src) + t);
+    return v;
+}
+
+// The chunk's tiles are in LDS (tiles4: kFinishLdsBytes): rows out.  t: thread index in the workgroup of 256 (8 row pairs x
+// 32 quads); nt: source tiles present.
+__device__ __forceinline__ void finish_emit(const wp_vp8_frame& fr, int ty, int c0, int t, int nt, const uint4* tiles4, bool shifted,
+                                            uint8_t* Yp, uint8_t* Up, uint8_t* Vp, const uint8_t* __restrict__ Ap, uint8_t* out) {
     const int mbw = fr.mbw, mbh = fr.mbh, width = fr.width, height = fr.height;
     const int shift = shifted ? kFiltShift : 0;
-    const int ntx = mbw + (shifted ? 1 : 0);
-    const int tx0 = c0 >> 4;                                      // (c0 + shift) >> 4: first source tile
-    const int nt = min(shifted ? kFinishTiles : kFinishTiles - 1, ntx - tx0);
-    const uint8_t* src = (shifted ? Sp + size_t(fr.stile_base) * kTileBytes : Rp + size_t(fr.mb_base) * kTileBytes)
-                       + (size_t(ty) * ntx + tx0) * kTileBytes;
-    if (t < nt * (kTileBytes / 16)) { const int i = t; const u32x4 v = WP_NT_LOAD(reinterpret_cast<const u32x4*>(src) + i); tiles4[i] = make_uint4(v.x, v.y, v.z, v.w); }
-    __syncthreads();
     const uint32_t* tiles32 = reinterpret_cast<const uint32_t*>(tiles4);
     const uint16_t* tiles16 = reinterpret_cast<const uint16_t*>(tiles4);
 
