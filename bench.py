@@ -159,6 +159,9 @@ def main():
         torch.cuda.synchronize()
 
     from webp_amd.device import LossyPipeline
+    if args.serial:
+        from webp_amd._lib import lib as _wl
+        _wl().wp_hint_finish_overlap(0)            # the finishing pass runs on its own here
     pipe = None if args.serial else LossyPipeline(device, split=args.split, finish_delay_us=args.finish_delay_us, one_launch=args.one_launch, workspaces=args.workspaces)
     if pipe is not None:
         for k in range(args.workspaces):

@@ -155,6 +155,11 @@ int wp_device_count(void);
  * launch, so that the split the library makes for batches beyond its band-sequence range (2^19 bands per persistent
  * workgroup, i.e. > 500 000 frames) can be exercised with a small batch.  0 restores the default. */
 int wp_debug_set_frames_per_launch(int frames);
+/* Tuning hint (no counterpart in the reference): will wp_vp8_finish_dev / wp_vp8_finish_range_dev share the GPU with another
+ * kernel of the caller (a pipelining caller runs them beside the next batch's wp_vp8_recon_filter_dev: the default, 1), or
+ * run on their own (0)?  Selects how much work a workgroup of the pass takes; results are identical either way.
+ * wp_vp8_decode_to_argb_dev, whose finishing pass follows its own kernel on one stream, always uses the second form. */
+int wp_hint_finish_overlap(int on);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Device-resident batch entry points                                                           */

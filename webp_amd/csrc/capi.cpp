@@ -21,7 +21,7 @@ int wpk_launch_vp8_filter(int n, int cus, const wp_vp8_frame* d_frames, const ui
                           const uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream);
 int wpk_launch_vp8_recon_filter(int n, int cus, const wp_vp8_frame* d_frames, int use_turns, const void* d_mb, const int16_t* d_coeff,
                                 const uint32_t* d_filt, uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream);
-int wpk_launch_vp8_finish(int n, int chunks, int tile_rows, const wp_vp8_frame* d_frames, const uint8_t* d_rtiles,
+int wpk_launch_vp8_finish(int n, int chunks, int tile_rows, int alone, const wp_vp8_frame* d_frames, const uint8_t* d_rtiles,
                           const uint8_t* d_stiles, int force_unshifted, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
                           const uint8_t* d_alpha, uint8_t* d_argb, hipStream_t stream);
 int wpk_launch_vp8_tile(int n, int grid_x, const wp_vp8_frame* d_frames, const uint8_t* d_y, const uint8_t* d_u,
@@ -183,13 +183,17 @@ FinishGeom finish_geom(int n, const wp_vp8_frame* f) {
     return g;
 }
 
+// set while an entry point runs the finishing pass right behind its own kernels on one stream (nothing shares the GPU with it)
+thread_local bool g_finish_alone = false;
+std::atomic<int> g_finish_overlap{1};      // wp_hint_finish_overlap
+
 int launch_finish(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint8_t* d_work, const Vp8Work& w, int force_unshifted,
                   uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, const uint8_t* d_alpha, uint8_t* d_argb, hipStream_t stream) {
     // the z dimension of the grid is the frame index (<= 65535 per launch)
     for (int first = 0; first < n; first += 65535) {
         const int cnt = std::min(65535, n - first);
         const FinishGeom g = finish_geom(cnt, fh + first);
-        const int e = wpk_launch_vp8_finish(cnt, g.chunks, g.rows, fd + first, d_work, d_work + w.r_bytes, force_unshifted,
+        const int e = wpk_launch_vp8_finish(cnt, g.chunks, g.rows, (g_finish_alone || !g_finish_overlap.load(std::memory_order_relaxed)) ? 1 : 0, fd + first, d_work, d_work + w.r_bytes, force_unshifted,
                                             d_y, d_u, d_v, d_alpha, d_argb, stream);
         if (e) return hip_fail(hipError_t(e), "vp8_finish launch");
     }
@@ -230,6 +234,11 @@ int wp_shutdown(void) { return WP_OK; }
 int wp_debug_set_frames_per_launch(int frames) {
     if (frames < 0) return fail(WP_ERR_INVALID, "negative frame count");
     g_launch_cap.store(frames, std::memory_order_relaxed);
+    return WP_OK;
+}
+
+int wp_hint_finish_overlap(int on) {
+    g_finish_overlap.store(on ? 1 : 0, std::memory_order_relaxed);
     return WP_OK;
 }
 
@@ -381,7 +390,10 @@ int wp_vp8_decode_to_argb_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame*
                               const uint8_t* d_alpha, uint8_t* d_argb, void* stream) {
     int rc = wp_vp8_recon_filter_dev(n, fh, fd, d_mb, d_filt, d_coeff, d_work, work_bytes, stream);      // one kernel for both
     if (rc) return rc;
-    return wp_vp8_finish_dev(n, fh, fd, d_work, work_bytes, d_y, d_u, d_v, d_alpha, d_argb, stream);
+    g_finish_alone = true;
+    rc = wp_vp8_finish_dev(n, fh, fd, d_work, work_bytes, d_y, d_u, d_v, d_alpha, d_argb, stream);
+    g_finish_alone = false;
+    return rc;
 }
 
 int wp_vp8_decode_to_argb_static_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint32_t* d_mb, const uint32_t* d_filt,

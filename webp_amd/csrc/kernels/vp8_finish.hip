@@ -13,10 +13,14 @@
 namespace wpk {
 
 #ifndef WP_FINISH_PER_WG
-#define WP_FINISH_PER_WG 1
+#define WP_FINISH_PER_WG 4
 #endif
-constexpr int kFinishPerWg = WP_FINISH_PER_WG;
+constexpr int kFinishPerWgShared = WP_FINISH_PER_WG;      // chunks per workgroup when the pass shares the GPU (see the kernel)
+#ifndef WP_FINISH_PRIO
+#define WP_FINISH_PRIO 1
+#endif
 
+template <int kFinishPerWg>
 __global__ __launch_bounds__(256)
 void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* __restrict__ Rp, const uint8_t* __restrict__ Sp,
                        int force_unshifted, uint8_t* Yp, uint8_t* Up, uint8_t* Vp, const uint8_t* __restrict__ Ap, uint8_t* out) {
@@ -24,14 +28,21 @@ void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* _
     const wp_vp8_frame& fr = frames[blockIdx.z];
     const bool shifted = !force_unshifted;
     const int t = int(threadIdx.x);
+    // Issue priority 1: above the residual phase of the one-kernel reconstruction + loop filter (0), level with its
+    // prediction (1), below its horizontal edges and i4 mini-steps (2).  At 0 the pass only got what that kernel left over and
+    // was what a pipelined step waited for (7.07 ms per 1024 x 1080p); at 1: 6.64, at 2: 6.72, at 3: 7.03 (the persistent
+    // kernel then pays more than the pass gains).  Alone on the GPU the priority changes nothing.
+    __builtin_amdgcn_s_setprio(WP_FINISH_PRIO);
     const int ty = blockIdx.y, c_first = blockIdx.x * (kFinishPerWg * kFinishCols);
     const int c_end = 16 * fr.mbw;
     if (ty >= fr.mbh + (shifted ? 1 : 0) || c_first >= c_end) return;
     // kFinishPerWg adjacent chunks per workgroup, the next chunk's tiles fetched into registers while the current one is
     // converted.  Built to test whether the pass, of which a CU holds only two workgroups beside the one-kernel
-    // reconstruction + loop filter, is bound there by the latency of its one load per workgroup: it is not -- with 2, 3, 4 or
-    // 8 chunks per workgroup (32 registers, same residency) a pipelined step takes 7.07 / 7.04 / 7.10 / 6.94 ms against 7.10
-    // with one, and the pass alone 2.93 - 3.14 ms against 2.84.  Default 1.
+    // reconstruction + loop filter, is bound there by the latency of its one load per workgroup: hardly -- at issue priority 0
+    // 2, 3, 4 or 8 chunks per workgroup (32 registers, same residency) give 7.07 / 7.04 / 7.10 / 6.94 ms per pipelined step
+    // against 7.10 with one; at priority 1 (below) 6.60 / 6.52 / 6.48 for 2 / 4 / 8 against 6.64.  The pass alone: 2.93 - 3.14
+    // ms against 2.84.  So: 4 when the caller runs the pass on its own (wp_vp8_finish[_range]_dev: what a pipelining caller
+    // uses), 1 inside wp_vp8_decode_to_argb_dev, where the pass follows the persistent kernel on the same stream.
     FinishSrc fs = finish_src(fr, ty, c_first, Rp, Sp, shifted);
     u32x4 nx = finish_fetch(fs, t);
     int nx_nt = fs.nt;
@@ -81,11 +92,15 @@ void vp8_tile_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* __r
 
 }  // namespace wpk
 
-extern "C" int wpk_launch_vp8_finish(int n, int chunks, int tile_rows, const wp_vp8_frame* d_frames, const uint8_t* d_rtiles,
+extern "C" int wpk_launch_vp8_finish(int n, int chunks, int tile_rows, int alone, const wp_vp8_frame* d_frames, const uint8_t* d_rtiles,
                                      const uint8_t* d_stiles, int force_unshifted, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
                                      const uint8_t* d_alpha, uint8_t* d_argb, hipStream_t stream) {
-    hipLaunchKernelGGL(wpk::vp8_finish_kernel, dim3((chunks + wpk::kFinishPerWg - 1) / wpk::kFinishPerWg, tile_rows, n), dim3(256), 0, stream,
-                       d_frames, d_rtiles, d_stiles, force_unshifted, d_y, d_u, d_v, d_alpha, d_argb);
+    if (alone)
+        hipLaunchKernelGGL(wpk::vp8_finish_kernel<1>, dim3(chunks, tile_rows, n), dim3(256), 0, stream,
+                           d_frames, d_rtiles, d_stiles, force_unshifted, d_y, d_u, d_v, d_alpha, d_argb);
+    else
+        hipLaunchKernelGGL(wpk::vp8_finish_kernel<wpk::kFinishPerWgShared>, dim3((chunks + wpk::kFinishPerWgShared - 1) / wpk::kFinishPerWgShared, tile_rows, n),
+                           dim3(256), 0, stream, d_frames, d_rtiles, d_stiles, force_unshifted, d_y, d_u, d_v, d_alpha, d_argb);
     return int(hipGetLastError());
 }
 
