@@ -27,6 +27,21 @@
 
 namespace wpk {
 
+// Issue priorities along a step (a wavefront close to publishing goes first): residuals + emit / hand-down, prediction +
+// vertical edges, i4 mini-steps, horizontal edges.  The finishing pass that shares the GPU with this kernel runs at 1.
+#ifndef WP_MB_PRIO_R
+#define WP_MB_PRIO_R 0
+#endif
+#ifndef WP_MB_PRIO_P
+#define WP_MB_PRIO_P 1
+#endif
+#ifndef WP_MB_PRIO_I4
+#define WP_MB_PRIO_I4 2
+#endif
+#ifndef WP_MB_PRIO_H
+#define WP_MB_PRIO_H 2
+#endif
+
 constexpr int kEdgeBytes = 32;      // per MB of a band's last row: 16 Y + 8 Cb + 8 Cr bytes of its unfiltered bottom row
 
 struct alignas(16) MbFilterTile {
@@ -195,7 +210,7 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
             prefetch(s, ln);
             WP_PROF_MARK(1);
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(WP_MB_PRIO_P);
 
             if (act) {
                 // ---- prepareYBR (Vp8Decoder.hx:541-577) ----
@@ -240,7 +255,7 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
             }
             // ---- luma, 4x4: block (bj, bi) is ready at mini-step bi + 2*bj ----
             if (__builtin_amdgcn_ballot_w64(act && !i16) != 0) {
-                __builtin_amdgcn_s_setprio(2);
+                __builtin_amdgcn_s_setprio(WP_MB_PRIO_I4);
                 const int my_t = bi + 2 * bj;
                 const int mode4 = int(((l < 8 ? rec.x : rec.y) >> (4 * (l & 7))) & 15);
                 for (int t = 0; t < 10; ++t) {
@@ -258,7 +273,7 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_s_setprio(1);
+                __builtin_amdgcn_s_setprio(WP_MB_PRIO_P);
             }
             if (act) {
                 // ---- chroma: one 8x8 predictor per plane, four 4x4 residual blocks each ----
@@ -353,7 +368,7 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_s_setprio(2);
+                __builtin_amdgcn_s_setprio(WP_MB_PRIO_H);
                 if (do_filter) {
                     // ---- horizontal edges: lane = pixel column; rows -4..15 relative to the MB ----
                     {
@@ -378,7 +393,7 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
             }
             WP_PROF_MARK(4);
 
-            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(WP_MB_PRIO_R);
             // ---- tell the band below how far this band's last row has got: the value of the PREVIOUS step, whose stores
             //      were issued a whole step ago (the release fence then does not wait for their acknowledgements) ----
             settle(rec_n2); settle(nl0); settle(nl1); settle(nwv); settle(nc0); settle(nc1); settle(top_n);
