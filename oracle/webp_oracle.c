@@ -1755,7 +1755,23 @@ int wo_decode(const uint8_t* data, int len, wo_image** out) {
     uint8_t* argb = NULL; int lw = 0, lh = 0;
     wo_image lossy; memset(&lossy, 0, sizeof lossy);
     wo_image* frames = NULL; int nframes = 0;
-    /* The reference first collects all chunks (decodeChunks :246-256), then processes them in order. */
+    /* The reference first collects all chunks (decodeChunks :246-256: a container error anywhere in the file is raised
+     * before any payload is looked at), then processes them in order. */
+    {
+        int p2 = pos, t2 = totalLen;
+        while (t2 > 0) {
+            if (len - p2 < 8) { rc = fail(WO_ERR_EOF, "Eof"); goto bad2; }
+            int32_t dl = (int32_t)rd32(data + p2 + 4);
+            p2 += 8;
+            if (dl < 0 || dl > len - p2) { rc = fail(WO_ERR_EOF, "Eof"); goto bad2; }
+            p2 += dl;
+            if ((dl & 1) == 1) {
+                if (p2 >= len) { rc = fail(WO_ERR_EOF, "Eof"); goto bad2; }
+                p2++; t2 -= 1;
+            }
+            t2 -= dl + 8;
+        }
+    }
     while (totalLen > 0) {
         if (len - pos < 8) { rc = fail(WO_ERR_EOF, "Eof"); goto bad2; }
         const uint8_t* id = data + pos;

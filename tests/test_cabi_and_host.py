@@ -83,12 +83,19 @@ def test_fixture_filter_records():
     (b"RIFF\x04\x00\x00\x00WEBP", "Invalid format: no VP8/VP8L chunk found"),
     (b"RIFF\x10\x00\x00\x00WEBPVP8L\x04\x00\x00\x00\x2e\x00\x00\x00", "vp8l: invalid header"),
     (b"RIFF\x16\x00\x00\x00WEBPVP8 \x0a\x00\x00\x00\x00\x00\x00\x9d\x01\x2b\x10\x00\x10\x00", "vp8: invalid format"),
+    # a bad payload FOLLOWED by a truncated chunk: decodeChunks (WebPDecoder.hx:246-256) collects every chunk before any
+    # payload is decoded, so the container error comes first
+    (b"RIFF\x40\x00\x00\x00WEBPVP8L\x04\x00\x00\x00\x2e\x00\x00\x00JUNK\x30\x00\x00\x00abcd", "Eof"),
 ])
 def test_host_parse_errors_match_reference_strings(data, msg):
     from webp_amd import parse, WebPError
     with pytest.raises(WebPError) as e:
         parse(data)
     assert msg in str(e.value)
+    from oracle import oracle
+    with pytest.raises(oracle.OracleError) as eo:
+        oracle.decode(data)
+    assert msg in str(eo.value)
 
 
 def test_truncated_stream_is_null_frame():

@@ -92,6 +92,25 @@ int parse_webp(const uint8_t* data, size_t len, wp_parsed& out, std::string& err
     bool lossy = false, lossless = false;
     ParsedFrame still;
     std::vector<ParsedFrame> frames;
+    // decodeChunks (:246-256) collects every chunk before any payload is decoded: a container error anywhere in the file
+    // comes before a payload's own error.  The same walk, without the payloads, first.
+    {
+        size_t p2 = pos;
+        int64_t r2 = remaining;
+        while (r2 > 0) {
+            if (len - p2 < 8) { err = "Eof"; return WP_ERR_EOF; }
+            const int32_t n = int32_t(le32(data + p2 + 4));
+            p2 += 8;
+            if (n < 0 || size_t(n) > len - p2) { err = "Eof"; return WP_ERR_EOF; }
+            p2 += size_t(n);
+            if (n & 1) {
+                if (p2 >= len) { err = "Eof"; return WP_ERR_EOF; }
+                ++p2;
+                r2 -= 1;
+            }
+            r2 -= int64_t(n) + 8;
+        }
+    }
     while (remaining > 0) {                                     // readRiffChunk :47-76
         if (len - pos < 8) { err = "Eof"; return WP_ERR_EOF; }
         const uint8_t* id = data + pos;
