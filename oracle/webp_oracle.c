@@ -1654,7 +1654,7 @@ static int readAlpha(const uint8_t* data, int len, int widthMinusOne, int height
     if (compression == 0) {
         int w = widthMinusOne + 1, h = heightMinusOne + 1;
         if (len < w * h) return fail(WO_ERR_FORMAT, "Failed to read alpha values: Eof");
-        uint8_t* alpha = (uint8_t*)malloc(w * h ? w * h : 1);
+        uint8_t* alpha = (uint8_t*)malloc((w * h) != 0 ? w * h : 1);
         memcpy(alpha, data, (size_t)w * h);
         *out = alpha; *outlen = w * h;
         return WO_OK;

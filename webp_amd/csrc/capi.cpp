@@ -19,6 +19,7 @@ int wpk_launch_vp8_recon(int n, int cus, const wp_vp8_frame* d_frames, const voi
                          uint8_t* d_rtiles, hipStream_t stream);
 int wpk_launch_vp8_filter(int n, int cus, const wp_vp8_frame* d_frames, const uint32_t* d_filt,
                           const uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream);
+int wpk_mb_wgs_per_cu(void);
 int wpk_launch_vp8_recon_filter(int n, int cus, const wp_vp8_frame* d_frames, int use_turns, const void* d_mb, const int16_t* d_coeff,
                                 const uint32_t* d_filt, uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream);
 int wpk_launch_vp8_finish(int n, int chunks, int tile_rows, int alone, const wp_vp8_frame* d_frames, const uint8_t* d_rtiles,
@@ -143,7 +144,7 @@ int frames_per_launch(int n, const wp_vp8_frame* f, int phases = 1) {      // ph
 // got the heaviest frame of a round gets the lightest of the next.
 void assign_turns(int n, wp_vp8_frame* f) {
     const int per = frames_per_launch(n, f);
-    const int grid = std::max(1, 2 * g_cus.load(std::memory_order_relaxed));      // WP_MB_WGS_PER_CU persistent workgroups per CU
+    const int grid = std::max(1, wpk_mb_wgs_per_cu() * g_cus.load(std::memory_order_relaxed));      // the kernel's persistent workgroups
     std::vector<uint32_t> order;
     for (int first = 0; first < n; first += per) {
         const int cnt = std::min(per, n - first);

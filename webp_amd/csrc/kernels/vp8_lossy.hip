@@ -60,6 +60,8 @@ extern "C" int wp_debug_profile_mb(unsigned long long* out, int reset) {
 }
 #endif
 
+extern "C" int wpk_mb_wgs_per_cu(void) { return wpk::kMbWGsPerCU; }
+
 // Tuning aid: resident workgroups per CU the runtime computes for the kernel (registers, LDS).
 extern "C" int wp_debug_mb_occupancy(void) {
     int n = 0;
