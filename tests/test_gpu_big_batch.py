@@ -129,6 +129,17 @@ def test_split_into_several_launches(big):
         _clear(db)
         db.decode_to_argb()
         _check_all(db, rb, "one-launch kernel, 300 frames each")
+        # the batch above was planned for ONE launch, so its frame schedule (wp_vp8_frame.turn) does not fit the four launches
+        # and each runs in slot order; planned with the split in force, every launch gets a schedule of its own
+        from webp_amd.device import DeviceLossyBatch
+        db2 = DeviceLossyBatch(rb, "cuda:0")
+        turns = [int(rb.desc[i].turn) for i in range(rb.n)]
+        for first in range(0, rb.n, 300):
+            assert sorted(turns[first:first + 300]) == list(range(min(300, rb.n - first)))
+        db2.decode_to_argb()
+        _check_all(db2, rb, "one-launch kernel, 300 frames each, scheduled per launch")
+        db2.finish()                                  # the finishing pass in the shape it takes beside another kernel
+        _check_all(db2, rb, "finishing pass, several chunks per workgroup")
     finally:
         check(L.wp_debug_set_frames_per_launch(0))
 
