@@ -146,5 +146,51 @@ def test_streaming_decode_equals_per_file_decode():
             assert np.array_equal(slab[it[name + "_off"]:it[name + "_off"] + w.size].numpy(), w), (paths[i % len(paths)], name)
         w = want["to_argb"]
         assert np.array_equal(argb[it["argb_off"]:it["argb_off"] + w.size].numpy(), w), paths[i % len(paths)]
-    with pytest.raises(ValueError, match="ALPH"):           # stills with alpha are refused, not decoded without their alpha
-        LossyStream(threads=2, chunk=2).decode([open(os.path.join(ROOT, "tests", "golden", "inputs", "a.webp"), "rb").read()])
+
+
+def _raw_alpha_still(src: bytes, filt: int, seed: int) -> bytes:
+    """A VP8X still made of `src`'s VP8 chunk and an uncompressed ALPH chunk (compression 0) with the given filter."""
+    import struct
+    pos, vp8, vp8x = 12, None, None
+    while pos + 8 <= len(src):
+        tag, n = src[pos:pos + 4], struct.unpack("<I", src[pos + 4:pos + 8])[0]
+        if tag == b"VP8 ":
+            vp8 = src[pos + 8:pos + 8 + n]
+        if tag == b"VP8X":
+            vp8x = src[pos + 8:pos + 8 + n]
+        pos += 8 + n + (n & 1)
+    w = 1 + int.from_bytes(vp8x[4:7], "little")
+    h = 1 + int.from_bytes(vp8x[7:10], "little")
+    rng = np.random.default_rng(seed)
+    plane = (rng.integers(0, 256, w * h, dtype=np.uint8) // (1 if filt == 0 else 16)).astype(np.uint8).tobytes()
+    chunk = lambda t, d: t + struct.pack("<I", len(d)) + d + (b"\0" if len(d) & 1 else b"")
+    body = b"WEBP" + chunk(b"VP8X", vp8x) + chunk(b"ALPH", bytes([filt << 2]) + plane) + chunk(b"VP8 ", vp8)
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def test_streaming_decode_of_stills_with_alpha():
+    """Stills with an ALPH chunk through LossyStream: VP8L-coded alpha (golden a.webp, libwebp's 720p streams with the
+    horizontal filter) and uncompressed alpha with every filter, mixed with opaque stills in one call; A,R,G,B and the
+    alpha plane itself (ImageData.Yuv420.a, WebPDecoder.hx:236-241) against the oracle."""
+    import glob
+    import os
+    import torch
+    from conftest import ROOT
+    from oracle import oracle
+    from webp_amd.streaming import LossyStream
+    rd = lambda p: open(p, "rb").read()
+    coded = [rd(os.path.join(ROOT, "tests", "golden", "inputs", "a.webp"))] + [rd(p) for p in sorted(glob.glob(os.path.join(ROOT, "bench_data", "lossy720_alpha_*.webp")))]
+    raw = [_raw_alpha_still(coded[1], f, 10 + f) for f in range(4)]
+    opaque = [rd(os.path.join(ROOT, "tests", "golden", "inputs", n + ".webp")) for n in ("1", "2")]
+    datas = [opaque[0], coded[0], raw[1], coded[1], opaque[1], raw[3], raw[0], coded[2], raw[2]]
+    argb, items, y, u, v = LossyStream(threads=4, chunk=4).decode(datas)
+    torch.cuda.synchronize()
+    for i, data in enumerate(datas):
+        want, it = oracle.decode(data), items[i]
+        w = want["to_argb"]
+        assert np.array_equal(argb[it["argb_off"]:it["argb_off"] + w.size].numpy(), w), i
+        if want["a"] is None:
+            assert it["alpha"] is None
+        else:
+            assert np.array_equal(it["alpha"], want["a"]), i
+        assert np.array_equal(y[it["y_off"]:it["y_off"] + want["y"].size].numpy(), want["y"]), i
