@@ -205,3 +205,33 @@ def test_alpha_unfilter_many_planes():
     check(lib().wp_alpha_unfilter(n, desc, vp(src), src.size, vp(out), out.size))
     for i, (w, h, f) in enumerate(dims):
         assert np.array_equal(out[desc[i].dst_off:desc[i].dst_off + w * h], want[i]), (i, w, h, f)
+
+
+def test_vp8l_chains_on_two_streams():
+    """A batch large enough (>= 64 Mpix) for the library to run the chains of frames with a predictor and of frames without
+    on two streams (vp8l.hip wpk_launch_vp8l): 40 predictor frames and 40 palette / subtract-green frames of 1024 x 1024,
+    every frame against the oracle."""
+    from oracle import oracle
+    from test_gpu_vp8l import _run_chain, _tiles
+    rng = np.random.default_rng(808)
+    w = h = 1024
+    cases, want = [], []
+    for i in range(80):
+        pix = rng.integers(0, 256, 4 * w * h, dtype=np.uint8)
+        if i % 2 == 0:
+            bits = 4
+            tp = _tiles(rng, w, h, bits, list(range(14)))
+            chain = [(2, 0, w, np.zeros(0, np.uint8)), (0, bits, w, tp)]
+            e = oracle.inverse_subtract_green(oracle.inverse_predictor(w, bits, tp, pix, h))
+        elif i % 4 == 1:
+            chain = [(2, 0, w, np.zeros(0, np.uint8))]
+            e = oracle.inverse_subtract_green(pix)
+        else:
+            pal = rng.integers(0, 256, 4 * 256, dtype=np.uint8)
+            chain = [(3, 0, w, pal)]
+            e = oracle.inverse_color_indexing(w, 0, pal, pix, h)
+        cases.append(dict(width=w, height=h, coded_width=w, pix=pix, transforms=chain))
+        want.append(np.ascontiguousarray(e.reshape(-1, 4)[:, [3, 0, 1, 2]]).reshape(-1))
+    got = _run_chain(cases, swizzle=1)
+    for i, (g, e) in enumerate(zip(got, want)):
+        assert np.array_equal(g, e), "frame %d" % i

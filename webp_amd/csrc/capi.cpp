@@ -20,6 +20,7 @@ int wpk_launch_vp8_recon(int n, int cus, const wp_vp8_frame* d_frames, const voi
 int wpk_launch_vp8_filter(int n, int cus, const wp_vp8_frame* d_frames, const uint32_t* d_filt,
                           const uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream);
 int wpk_mb_wgs_per_cu(void);
+int wpk_vp8l_side_init(int dev);
 int wpk_launch_vp8_recon_filter(int n, int cus, const wp_vp8_frame* d_frames, int use_turns, const void* d_mb, const int16_t* d_coeff,
                                 const uint32_t* d_filt, uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream);
 int wpk_launch_vp8_finish(int n, int chunks, int tile_rows, int alone, const wp_vp8_frame* d_frames, const uint8_t* d_rtiles,
@@ -226,6 +227,8 @@ int wp_init(int device) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     g_cus.store(prop.multiProcessorCount, std::memory_order_relaxed);
+    const int side_rc = wpk_vp8l_side_init(dev);  // the VP8L chain's side stream (streaming passes beside the predictor)
+    if (side_rc) return hip_fail(hipError_t(side_rc), "side stream");
     void* sp = nullptr;
     return static_scratch(&sp);             // set-up is where the static workspace's address on this device is looked up
 }
