@@ -113,9 +113,9 @@ _PIPELINE_STREAMS = {}
 
 def pipeline_streams(device):
     """The two HIP streams every LossyPipeline of this process uses on `device` (default priority), created once.  A
-    process therefore never holds more than two extra streams per device however many pipelines it builds: HIP multiplexes
-    streams onto GPU_MAX_HW_QUEUES (4) hardware queues, and a stream whose barrier packet waits for a kernel that sits
-    behind it on the same hardware queue can never be released ("the recorded hang")."""
+    process therefore never holds more than two extra streams per device however many pipelines it builds, and none with a
+    priority: round 1's per-object streams, one of them high-priority, once stalled for good in a process that had created
+    many ("the round-1 hang")."""
     device = torch.device(device)
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _PIPELINE_STREAMS:

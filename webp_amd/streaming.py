@@ -22,9 +22,8 @@ _STREAMS = {}
 
 
 def stream_streams(device):
-    """The three streams (upload, compute, download) every LossyStream of the process shares on a device: a process that
-    holds more HIP streams than hardware queues can dead-lock a barrier packet behind the kernel it waits for (DESIGN.md
-    5.1), so streams are not created per object."""
+    """The three streams (upload, compute, download) every LossyStream of the process shares on a device: the number of
+    streams the library creates per process stays fixed, whatever the number of objects."""
     device = torch.device(device)
     key = device.index or 0
     if key not in _STREAMS:
