@@ -238,10 +238,12 @@ def end_to_end(device, n=1024, threads=16, chunk=32):
     stream = LossyStream(device, threads=threads, chunk=chunk, planes=True)
     stream.decode(datas)                                       # warm-up: streams, pinned staging and output slabs (a serving loop keeps them)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    argb, items, y, u, v = stream.decode(datas)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = 1e9
+    for _ in range(2):                                         # host-side timing on a shared machine: the better of two runs
+        t0 = time.perf_counter()
+        argb, items, y, u, v = stream.decode(datas)
+        torch.cuda.synchronize()
+        dt = min(dt, time.perf_counter() - t0)
     idx = sorted(set([0, chunk - 1, chunk, n // 2, n - 1]))
     for i in idx:
         want = oracle.decode(datas[i])
