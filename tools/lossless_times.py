@@ -1,5 +1,6 @@
 """Device-resident timing of the VP8L inverse-transform chain (cfg 3: 1080p lossless) and its per-kernel split:
-  python tools/lossless_times.py [images]      (run under rocprofv3 --kernel-trace --stats for the per-kernel table)"""
+  python tools/lossless_times.py [images]      (run under rocprofv3 --kernel-trace --stats for the per-kernel table)
+  python tools/lossless_times.py [images] [stream index]   one of the bench streams only"""
 import ctypes, glob, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,6 +12,8 @@ from webp_amd.decoder import LosslessBatch
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 paths = sorted(glob.glob(os.path.join(root, "bench_data", "lossless1080_*.webp")))
+if len(sys.argv) > 2:                # one of the streams only: python tools/lossless_times.py 1024 <index>
+    paths = [paths[int(sys.argv[2])]]
 files = [parse(open(p, "rb").read()) for p in paths]
 frames = [files[i % len(files)].frames[0] for i in range(n)]
 b = LosslessBatch(frames)

@@ -368,6 +368,9 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
             for (int g4 = 0; g4 < kPC / 4; ++g4) { nx_mode[g4] = 0; nx_cc[g4] = 0; }
             auto fetch = [&](int kk) {
                 if (!(row_ok && kk >= 0 && kk < n_chunks)) return;
+#ifdef WP_KO_FETCH                                  // timing experiment only: one load per row
+                if (kk > 0) return;
+#endif
                 const int xx = kPC * kk;
                 if (xx + kPC <= w) {
 #pragma unroll
@@ -406,9 +409,105 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                 }
             }
 
-            for (int c = 0; c < n_steps; ++c) {
+#ifndef WP_PRED_NO_STAGE
+            // output flush, per lane and band: the two rows (mod 4) this lane flushes a piece of, their byte offsets in the
+            // frame's result (a frame is at most 16384 x 16384 pixels: 32 bits) and the lane's 4-pixel piece of a 32-pixel run
+            const int fl_x = 4 * (r & 7);
+            const uint32_t w4 = 4u * uint32_t(w);
+            int fl_row[2];
+            uint32_t fl_off[2];
+#pragma unroll
+            for (int round = 0; round < 2; ++round) {
+                fl_row[round] = 4 * ((r >> 3) + 8 * round);
+                fl_off[round] = uint32_t(band * kPredRows + fl_row[round]) * w4 + 4u * uint32_t(fl_x);
+            }
+#endif
+            for (int c = 0;; ++c) {
                 const int k = c - r;
                 const bool act = row_ok && k >= 0 && k < n_chunks;
+                // this step's inputs were fetched during the previous step (a lane's first chunk one step before it starts).
+                // Taking them is the step's one wait on memory, and it comes first: everything the wavefront has in flight
+                // was issued near the top of the previous step, a whole step ago.
+                uint32_t in[kPC], cc_of[kPC / 4];
+                int mode_of[kPC / 4];
+                // (real moves, hidden from the register coalescer: left to itself it loads the next step's inputs into fresh
+                // registers and moves them over at the END of this step, behind an s_waitcnt vmcnt(0) that undoes the prefetch)
+#pragma unroll
+                for (int j = 0; j < kPC; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(in[j]) : "v"(nx_in[j]));
+#pragma unroll
+                for (int g4 = 0; g4 < kPC / 4; ++g4) {
+                    uint32_t m_;
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(m_) : "v"(nx_mode[g4]));
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(cc_of[g4]) : "v"(nx_cc[g4]));
+                    mode_of[g4] = int(m_ & 15);
+                }
+                // ---- what step c-1 left behind goes to memory NOW, before this step's loads are requested: the stores then
+                // have the whole step to land.  Issued at the end of step c-1 instead they stood between the wavefront and
+                // its next inputs (vmcnt counts in order) and under the release fence of the progress counter: with four
+                // wavefronts per SIMD the store latency of every step was exposed (r02 PMC: the wavefronts spent half their
+                // time in s_waitcnt with the VALUs 42 % busy).
+                if (c > 0) {
+                    const int cp = c - 1, kp = cp - r;
+                    if (has_below && pending_publish) {
+                        // the row announced was stored a step ago: the release fence finds nothing left to wait for
+                        publish_progress(&progress[wave], pending_publish);
+                        pending_publish = 0;
+                    }
+                    if (keep_raw && row_ok && kp >= 0 && kp < n_chunks) {      // P1: the chunk this lane produced in step c-1
+                        const int xp = kPC * kp;
+                        if (xp + kPC <= w) {
+#pragma unroll
+                            for (int g4 = 0; g4 < kPC / 4; ++g4) {
+                                Px4 v;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v.v[j] = P1[4 * g4 + j];
+                                *reinterpret_cast<Px4*>(row + xp + 4 * g4) = v;
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < kPC; ++j) if (xp + j < w) row[xp + j] = P1[j];
+                        }
+                    }
+#if !defined(WP_PRED_NO_STAGE) && !defined(WP_KO_FLUSH)
+                    if (to_out) {
+                        // rows whose chunk index was 3 mod 4 in step c-1 have a complete 128-byte run in LDS: rows r0, r0 + 4, ...
+                        // (16 of them: two rounds of 8 rows x 8 lanes); a row that ended on another chunk index flushes what it
+                        // has.  What depends on the lane alone was computed once per band (fl_row, fl_off, fl_x).
+                        __builtin_amdgcn_wave_barrier();
+                        const int r0 = (cp + 1) & 3;
+                        const uint32_t r0_off = uint32_t(r0) * w4;
+#pragma unroll
+                        for (int round = 0; round < 2; ++round) {
+                            const int rr = fl_row[round] + r0;
+                            const int kk = cp - rr;                                 // (kk & 3) == 3 by construction
+                            const int x = (kk >> 2) * 32 + fl_x;
+                            if (kk >= 0 && kk < n_chunks && rr < rows_here && x < w) {
+                                const uint4 v = *reinterpret_cast<const uint4*>(&stage[wave][rr][fl_x]);
+                                uint8_t* dst = reinterpret_cast<uint8_t*>(obase) + (fl_off[round] + r0_off + uint32_t(kk >> 2) * 128u);
+                                if (x + 4 <= w) { Px4 o; o.v[0] = v.x; o.v[1] = v.y; o.v[2] = v.z; o.v[3] = v.w; *reinterpret_cast<Px4*>(dst) = o; }
+                                else { uint32_t* d = reinterpret_cast<uint32_t*>(dst); d[0] = v.x; if (x + 1 < w) d[1] = v.y; if (x + 2 < w) d[2] = v.z; }
+                            }
+                        }
+                        if (((n_chunks - 1) & 3) != 3 && r < 8) {                   // the row that has just produced its last chunk
+                            const int rr = cp - (n_chunks - 1);
+                            const int x = ((n_chunks - 1) >> 2) * 32 + fl_x;
+                            if (rr >= 0 && rr < rows_here && x < w) {
+                                const uint4 v = *reinterpret_cast<const uint4*>(&stage[wave][rr][fl_x]);
+                                uint32_t* d = obase + (long long)(band * kPredRows + rr) * w + x;
+                                d[0] = v.x; if (x + 1 < w) d[1] = v.y; if (x + 2 < w) d[2] = v.z; if (x + 3 < w) d[3] = v.w;
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+#endif
+                    if (has_below) {
+                        // the band's last row: what it has reached is announced at the top of the next step
+                        const int k_last = cp - (kPredRows - 1);
+                        if (k_last >= 0 && (((k_last + 1) * kPC) % kPredPublishPx == 0 || k_last == n_chunks - 1))
+                            pending_publish = (q << kPredSeqShift) | uint32_t(min(kPC * (k_last + 1), w));
+                    }
+                }
+                if (c == n_steps) break;
                 // ---- chunk k of the row above: lane r-1's previous outputs, or memory for the band's first row
 #pragma unroll
                 for (int j = 0; j < kPC; ++j) T4[j] = from_lane_above(P1[j]);
@@ -429,14 +528,7 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                         }
                     }
                 }
-                // this step's inputs were fetched during the previous step; the next step's are requested now and land
-                // while this chunk is being computed (a lane's first chunk is requested one step before it starts)
-                uint32_t in[kPC], cc_of[kPC / 4];
-                int mode_of[kPC / 4];
-#pragma unroll
-                for (int j = 0; j < kPC; ++j) in[j] = nx_in[j];
-#pragma unroll
-                for (int g4 = 0; g4 < kPC / 4; ++g4) { mode_of[g4] = int(nx_mode[g4] & 15); cc_of[g4] = nx_cc[g4]; }
+                // the next step's inputs are requested now and land while this chunk is being computed
                 fetch(k + 1);
                 const int x0 = kPC * k;
                 uint32_t res[kPC];
@@ -551,20 +643,6 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                     }
                 }
                 if (act) {
-                    if (keep_raw) {
-                        if (x0 + kPC <= w) {
-#pragma unroll
-                            for (int g4 = 0; g4 < kPC / 4; ++g4) {
-                                Px4 v;
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) v.v[j] = res[4 * g4 + j];
-                                *reinterpret_cast<Px4*>(row + x0 + 4 * g4) = v;
-                            }
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < kPC; ++j) if (x0 + j < w) row[x0 + j] = res[j];
-                        }
-                    }
                     if (to_out) {            // final pixels: R += G, B += G if a subtract-green follows, then the byte order asked for
                         uint32_t fin[kPC];
 #pragma unroll
@@ -594,37 +672,6 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                     TLfirst = T4[kPC - 1];
 #pragma unroll
                     for (int j = 0; j < kPC; ++j) P1[j] = res[j];
-                }
-#ifndef WP_PRED_NO_STAGE
-                if (to_out) {
-                    // rows whose chunk index is 3 mod 4 in this step have a complete 128-byte run in LDS: rows r0, r0 + 4, ...
-                    // (16 of them: two rounds of 8 rows x 8 lanes); a row that ends on another chunk index flushes what it has
-                    __builtin_amdgcn_wave_barrier();
-                    auto flush_row = [&](int rr, int piece) {
-                        const int kk = c - rr, yy = band * kPredRows + rr;
-                        if (rr < 0 || rr >= kPredRows || kk < 0 || kk >= n_chunks || yy >= h) return;
-                        const int x = (kk >> 2) * (4 * kPC) + 4 * piece;
-                        if (x >= w) return;
-                        const uint4 v = *reinterpret_cast<const uint4*>(&stage[wave][rr][4 * piece]);
-                        uint32_t* dst = obase + (long long)yy * w + x;
-                        if (x + 4 <= w) { Px4 o; o.v[0] = v.x; o.v[1] = v.y; o.v[2] = v.z; o.v[3] = v.w; *reinterpret_cast<Px4*>(dst) = o; }
-                        else { dst[0] = v.x; if (x + 1 < w) dst[1] = v.y; if (x + 2 < w) dst[2] = v.z; }
-                    };
-                    const int r0 = (c + 1) & 3;
-#pragma unroll
-                    for (int round = 0; round < 2; ++round) flush_row(r0 + 4 * ((r >> 3) + 8 * round), r & 7);
-                    if (((n_chunks - 1) & 3) != 3 && r < 8) flush_row(c - (n_chunks - 1), r);
-                    __builtin_amdgcn_wave_barrier();
-                }
-#endif
-                if (has_below) {
-                    // What is announced is the count reached two steps ago: its stores have had two steps to land, so the
-                    // release fence (s_waitcnt vmcnt(0)) does not stall the band on the stores it has only just issued.
-                    const int k_last = c - (kPredRows - 1);
-                    if (k_last >= 0 && (((k_last + 1) * kPC) % kPredPublishPx == 0 || k_last == n_chunks - 1)) {
-                        if (pending_publish) publish_progress(&progress[wave], pending_publish);
-                        pending_publish = (q << kPredSeqShift) | uint32_t(min(kPC * (k_last + 1), w));
-                    }
                 }
             }
             if (has_below && pending_publish) publish_progress(&progress[wave], pending_publish);      // the band's last rows are out
