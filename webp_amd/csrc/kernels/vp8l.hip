@@ -40,6 +40,8 @@ __device__ __forceinline__ uint32_t add_px(uint32_t a, uint32_t b) {
 // per-byte floor((a + b) / 2)  (Transform.hx:283-285 avg2)
 __device__ __forceinline__ uint32_t avg_px(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0u); }   // v_lerp_u8: (a + b + 0) >> 1 per byte
 
+typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));                   // one 16-byte access, 16-byte aligned (LDS)
+typedef uint32_t U32x4u __attribute__((ext_vector_type(4), aligned(4)));       // ... dword-aligned (pixel rows)
 struct __attribute__((aligned(4))) Px4 { uint32_t v[4]; };      // four pixels, dword-aligned (rows are not 16-byte aligned in general)
 
 // ---------------------------------------------------------------- pass fusion
@@ -482,9 +484,12 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                             const int kk = cp - rr;                                 // (kk & 3) == 3 by construction
                             const int x = (kk >> 2) * 32 + fl_x;
                             if (kk >= 0 && kk < n_chunks && rr < rows_here && x < w) {
-                                const uint4 v = *reinterpret_cast<const uint4*>(&stage[wave][rr][fl_x]);
+                                // (the four dwords are pinned as one register tuple: the row's ragged end below does not use
+                                // the fourth, and the compiler would otherwise split the read and the store into 12 + 4 bytes)
+                                U32x4 v = *reinterpret_cast<const U32x4*>(&stage[wave][rr][fl_x]);
+                                asm volatile("" : "+v"(v));
                                 uint8_t* dst = reinterpret_cast<uint8_t*>(obase) + (fl_off[round] + r0_off + uint32_t(kk >> 2) * 128u);
-                                if (x + 4 <= w) { Px4 o; o.v[0] = v.x; o.v[1] = v.y; o.v[2] = v.z; o.v[3] = v.w; *reinterpret_cast<Px4*>(dst) = o; }
+                                if (x + 4 <= w) *reinterpret_cast<U32x4u*>(dst) = v;
                                 else { uint32_t* d = reinterpret_cast<uint32_t*>(dst); d[0] = v.x; if (x + 1 < w) d[1] = v.y; if (x + 2 < w) d[2] = v.z; }
                             }
                         }
