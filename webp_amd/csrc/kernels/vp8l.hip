@@ -362,10 +362,14 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
             uint32_t pending_publish = 0;
             // A step's own inputs (its 8 pixels, the tile modes of its two 4-pixel groups, the cross-colour multipliers)
             // depend on nothing the wavefront computes, so they are fetched one step ahead: with a few bands of a frame in
-            // flight there are too few wavefronts per SIMD to hide a load issued where it is used.
-            uint32_t nx_in[kPC], nx_mode[kPC / 4], nx_cc[kPC / 4];
+            // flight there are too few wavefronts per SIMD to hide a load issued where it is used.  Pixels come as PAIRS of
+            // chunks, 64 bytes per lane every other step: every lane reads its own row, a CU's 16 wavefronts keep 1024
+            // cache lines in use and the 32 KB L1 holds 256, so whatever part of a 64-byte request is not taken at once
+            // is requested from L2 again (r02 PMC: 2.2 requests per 64 bytes read, the L1 stalled on pending requests
+            // three quarters of the time).
+            uint32_t nx_in[kPC], nx_in2[kPC], nx_mode[kPC / 4], nx_cc[kPC / 4];       // (two arrays: one indexed by k & 1 would go to scratch)
 #pragma unroll
-            for (int j = 0; j < kPC; ++j) nx_in[j] = 0;
+            for (int j = 0; j < kPC; ++j) { nx_in[j] = 0; nx_in2[j] = 0; }
 #pragma unroll
             for (int g4 = 0; g4 < kPC / 4; ++g4) { nx_mode[g4] = 0; nx_cc[g4] = 0; }
             auto fetch = [&](int kk) {
@@ -374,16 +378,22 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                 if (kk > 0) return;
 #endif
                 const int xx = kPC * kk;
-                if (xx + kPC <= w) {
+                if ((kk & 1) == 0) {                // a pair starts: both of its chunks
+                    if (xx + 2 * kPC <= w) {
 #pragma unroll
-                    for (int g4 = 0; g4 < kPC / 4; ++g4) {
-                        const Px4 v = *reinterpret_cast<const Px4*>(row + xx + 4 * g4);
+                        for (int g4 = 0; g4 < kPC / 4; ++g4) {
+                            const Px4 v = *reinterpret_cast<const Px4*>(row + xx + 4 * g4);
+                            const Px4 v2 = *reinterpret_cast<const Px4*>(row + xx + kPC + 4 * g4);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) nx_in[4 * g4 + j] = v.v[j];
+                            for (int j = 0; j < 4; ++j) { nx_in[4 * g4 + j] = v.v[j]; nx_in2[4 * g4 + j] = v2.v[j]; }
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < kPC; ++j) {
+                            nx_in[j] = (xx + j < w) ? row[xx + j] : 0u;
+                            nx_in2[j] = (xx + kPC + j < w) ? row[xx + kPC + j] : 0u;
+                        }
                     }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < kPC; ++j) nx_in[j] = (xx + j < w) ? row[xx + j] : 0u;
                 }
 #pragma unroll
                 for (int g4 = 0; g4 < kPC / 4; ++g4) {
@@ -435,7 +445,10 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                 // (real moves, hidden from the register coalescer: left to itself it loads the next step's inputs into fresh
                 // registers and moves them over at the END of this step, behind an s_waitcnt vmcnt(0) that undoes the prefetch)
 #pragma unroll
-                for (int j = 0; j < kPC; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(in[j]) : "v"(nx_in[j]));
+                for (int j = 0; j < kPC; ++j) {
+                    const uint32_t mine = (k & 1) ? nx_in2[j] : nx_in[j];     // the pair's first or second chunk
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(in[j]) : "v"(mine));
+                }
 #pragma unroll
                 for (int g4 = 0; g4 < kPC / 4; ++g4) {
                     uint32_t m_;
