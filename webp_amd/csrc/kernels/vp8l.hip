@@ -587,30 +587,31 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                         const bool plain = m == m0 && y > 0 && xg > 0 && xg + 4 <= w;
                         constexpr uint32_t kNoTR = 0xF9D7u;       // modes 0,1,2,4,6,7,8,11,12,13,14,15
                         if (__builtin_amdgcn_ballot_w64(!plain) == 0 && ((kNoTR >> m0) & 1u)) {
-                            uint32_t L = Lpx;
+                            // (the switch sits outside the pixel loop: one branch sequence per group, not per pixel)
+                            auto run4 = [&](auto pred) __attribute__((always_inline)) {
+                                uint32_t L = Lpx;
 #pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) {
-                                const int j = 4 * g4 + jj;
-                                const uint32_t T = T4[j];
-                                const uint32_t TL = j ? T4[j - 1] : TLfirst;
-                                uint32_t pr;
-                                switch (m0) {
-                                case 0: pr = 0xff000000u; break;
-                                case 1: pr = L; break;
-                                case 2: pr = T; break;
-                                case 4: pr = TL; break;
-                                case 6: pr = avg_px(L, TL); break;
-                                case 7: pr = avg_px(L, T); break;
-                                case 8: pr = avg_px(TL, T); break;
-                                case 11: pr = __builtin_amdgcn_sad_u8(TL, T, 0u) < __builtin_amdgcn_sad_u8(TL, L, 0u) ? L : T; break;
-                                case 12: pr = predict_px(12, L, T, TL, 0u); break;
-                                case 13: pr = predict_px(13, L, T, TL, 0u); break;
-                                default: pr = 0u; break;      // 14, 15: nothing is added
+                                for (int jj = 0; jj < 4; ++jj) {
+                                    const int j = 4 * g4 + jj;
+                                    L = add_px(in[j], pred(L, T4[j], j ? T4[j - 1] : TLfirst));
+                                    res[j] = L;
                                 }
-                                L = add_px(in[j], pr);
-                                res[j] = L;
+                                Lpx = L;
+                            };
+                            switch (m0) {
+                            case 0: run4([](uint32_t, uint32_t, uint32_t) { return 0xff000000u; }); break;
+                            case 1: run4([](uint32_t L, uint32_t, uint32_t) { return L; }); break;
+                            case 2: run4([](uint32_t, uint32_t T, uint32_t) { return T; }); break;
+                            case 4: run4([](uint32_t, uint32_t, uint32_t TL) { return TL; }); break;
+                            case 6: run4([](uint32_t L, uint32_t, uint32_t TL) { return avg_px(L, TL); }); break;
+                            case 7: run4([](uint32_t L, uint32_t T, uint32_t) { return avg_px(L, T); }); break;
+                            case 8: run4([](uint32_t, uint32_t T, uint32_t TL) { return avg_px(TL, T); }); break;
+                            case 11: run4([](uint32_t L, uint32_t T, uint32_t TL) {
+                                    return __builtin_amdgcn_sad_u8(TL, T, 0u) < __builtin_amdgcn_sad_u8(TL, L, 0u) ? L : T; }); break;
+                            case 12: run4([](uint32_t L, uint32_t T, uint32_t TL) { return predict_px(12, L, T, TL, 0u); }); break;
+                            case 13: run4([](uint32_t L, uint32_t T, uint32_t TL) { return predict_px(13, L, T, TL, 0u); }); break;
+                            default: run4([](uint32_t, uint32_t, uint32_t) { return 0u; }); break;      // 14, 15: nothing is added
                             }
-                            Lpx = L;
                             continue;
                         }
                     }
