@@ -342,7 +342,6 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
             // hundred): (bands - 1) x 64 rows x skew + chunks per row steps, so the skew is what counts.
             const int n_steps = n_chunks + (rows_here - 1);
             uint32_t* row = base + (long long)(row_ok ? y : 0) * w;
-            const uint32_t* above_row = base + (long long)(y > 0 ? y - 1 : 0) * w;
             const uint8_t* tile_row = tiles + 4 * ((row_ok ? y : 0) >> bits) * tpr;
             const uint32_t* cc_row = cc_tiles + ((row_ok ? y : 0) >> cc_bits) * cc_tpr;
 #ifdef WP_PRED_NO_STAGE
@@ -352,11 +351,12 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
             const bool keep_raw = !to_out || (has_below && r == kPredRows - 1);
 
             uint32_t P1[kPC], T4[kPC];              // my previous chunk's outputs (what the row below fetches); row above, this chunk
-            uint32_t An[kPC + 1];                   // band's first row: chunk c+1 of the row above and the pixel after it, read a step ahead
+            // band's first row: chunk c+1 of the row above the band and the pixel after it, read a step ahead -- one pixel per
+            // lane (lanes 0..kPC), handed to lane 0 with v_readlane: one load instruction per step instead of nine
+            uint32_t an_v = 0;
+            const uint32_t* const band_above = base + (long long)(has_above ? band * kPredRows - 1 : 0) * w;
 #pragma unroll
             for (int j = 0; j < kPC; ++j) { P1[j] = 0; T4[j] = 0; }
-#pragma unroll
-            for (int j = 0; j <= kPC; ++j) An[j] = 0;
             uint32_t TLfirst = 0, Lpx = 0, first_px = 0;
             uint32_t avail = 0;                     // pixels of the row above known to be finished (band boundary)
             uint32_t pending_publish = 0;
@@ -415,10 +415,7 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
             };
             if (has_above) {
                 wait_above(uint32_t(min(kPC + 1, w)));
-                if (r == 0) {
-#pragma unroll
-                    for (int j = 0; j <= kPC; ++j) An[j] = (j < w) ? above_row[j] : 0u;
-                }
+                if (r <= kPC && r < w) an_v = band_above[r];
             }
 
 #ifndef WP_PRED_NO_STAGE
@@ -531,19 +528,19 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                 for (int j = 0; j < kPC; ++j) T4[j] = from_lane_above(P1[j]);
                 uint32_t tr_mem = 0;
                 if (has_above) {
-                    if (r == 0) {
+                    uint32_t an_now;
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(an_now) : "v"(an_v));
 #pragma unroll
-                        for (int j = 0; j < kPC; ++j) T4[j] = An[j];
-                        tr_mem = An[kPC];
+                    for (int j = 0; j < kPC; ++j) {
+                        const uint32_t a = uint32_t(__builtin_amdgcn_readlane(int(an_now), j));
+                        T4[j] = r == 0 ? a : T4[j];
                     }
+                    tr_mem = uint32_t(__builtin_amdgcn_readlane(int(an_now), kPC));
                     if (c + 1 < n_chunks) {
-                        // lane 0 is about to read pixels up to kPC*(c+2) of row y-1
+                        // lane 0 is about to read pixels up to kPC*(c+2) of the row above the band
                         wait_above(uint32_t(min(kPC * (c + 2) + 1, w)));
-                        if (r == 0) {
-                            const int x1 = kPC * (c + 1);
-#pragma unroll
-                            for (int j = 0; j <= kPC; ++j) An[j] = (x1 + j < w) ? above_row[x1 + j] : 0u;
-                        }
+                        const int xa = kPC * (c + 1) + r;
+                        if (r <= kPC && xa < w) an_v = band_above[xa];
                     }
                 }
                 // the next step's inputs are requested now and land while this chunk is being computed
