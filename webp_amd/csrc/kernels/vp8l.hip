@@ -895,12 +895,23 @@ int grid_for(long long items, int n_frames) {
 // the chain streams.  Frames are independent, so the launcher splits them into those whose chain holds a predictor and those
 // whose does not and -- given a side stream for the device (created by wp_init) -- runs the second group's chains beside the
 // first's instead of after them: one fork before, one join after; every kernel skips the frames of the other group.
-// 1024 x 1080p, two thirds of the frames with a predictor, one third palette images: 6.99 -> 6.60 ms (the streaming kernels
-// started at once, before the persistent predictor kernel was placed: 7.80 ms; held back 20 ... 1000 us: 6.59 ... 6.81).
+// 1024 x 1080p, two thirds of the frames with a predictor, one third palette images: 5.39 -> 4.63 ms (see the delay below).
 // Without a side stream (wp_init never ran for the device), or with one group only, the passes run one after the other as
 // before.  The enqueue sequence is short and guarded, so that the fork / join events of concurrent callers do not interleave.
+// The predictor pass is a chain of dependent steps per frame, and towards its end most of a frame's wavefronts have run out
+// of bands: the other group's streaming kernels cost least there.  So the side stream is held back for a share of the
+// predictor pass's estimated duration (steps of its longest frame x the measured time of a step x rounds of 1024 frames);
+// 1024 x 1080p, 683 of them with a predictor (estimate 3.9 ms, measured alone 4.0): held back 40 us 4.91 ms, 0.4 of the
+// estimate 4.83, 0.5 4.73, 0.6 4.63, 0.75 4.73, 0.85 4.91; no side stream 5.39; streaming kernels placed first 6.1.  An
+// estimate that is off costs a few per cent either way.
 #ifndef WP_VP8L_SIDE_DELAY_US
-#define WP_VP8L_SIDE_DELAY_US 40
+#define WP_VP8L_SIDE_DELAY_US 40            // at least
+#endif
+#ifndef WP_VP8L_SIDE_DELAY_SHARE
+#define WP_VP8L_SIDE_DELAY_SHARE 0.6
+#endif
+#ifndef WP_VP8L_STEP_NS
+#define WP_VP8L_STEP_NS 2600                // one predictor step (8 pixels of 64 rows) with 3 - 4 wavefronts per SIMD
 #endif
 namespace wpk {
 // Holds a stream back for about `us` microseconds (one wavefront): the persistent predictor kernel has to be placed on the
@@ -948,13 +959,27 @@ extern "C" int wpk_launch_vp8l(int n, const wp_vp8l_frame* fh, const wp_vp8l_fra
         const wp_vp8l_frame* fdc = fd + first;
         const int gx = grid_for(max_px, cnt);
         bool any_p = false, any_s = false;
-        long long px = 0;
+        long long px = 0, pred_steps = 0;
+        int n_pred = 0;
         for (int i = first; i < first + cnt; ++i) {
-            if (with_predictor(i)) any_p = true; else any_s = true;
+            if (with_predictor(i)) {
+                any_p = true;
+                ++n_pred;
+                const long long bands = (fh[i].height + kPredRows - 1) / kPredRows;
+                pred_steps = std::max(pred_steps, (bands + kPredWaves - 1) / kPredWaves * ((fh[i].width + kPC - 1) / kPC + kPredRows - 1));
+            } else {
+                any_s = true;
+            }
             px += (long long)fh[i].width * fh[i].height;
         }
+        const double pred_us = double(pred_steps) * WP_VP8L_STEP_NS * 1e-3 * ((n_pred + 1023) / 1024);
+        const int delay_us = int(std::min(20000.0, std::max(double(WP_VP8L_SIDE_DELAY_US), WP_VP8L_SIDE_DELAY_SHARE * pred_us)));
         // two streams pay for themselves on large batches only: the second one is held back 40 us (see delay_kernel)
+#ifdef WP_VP8L_NO_FORK                     // tuning builds: one stream whatever the batch
+        const bool fork = false;
+#else
         const bool fork = have_side && any_p && any_s && px >= (64LL << 20);
+#endif
         // the chains of group `only` (0: every frame) on stream st
         auto chains = [&](int only, hipStream_t st) {
             for (int pass = 0; pass < WP_VP8L_MAX_TRANSFORMS; ++pass) {
@@ -978,7 +1003,7 @@ extern "C" int wpk_launch_vp8l(int n, const wp_vp8l_frame* fh, const wp_vp8l_fra
             hipStream_t side = g_side[dev];
             if (hipEventRecord(g_fork[dev], stream) != hipSuccess || hipStreamWaitEvent(side, g_fork[dev], 0) != hipSuccess) return int(hipGetLastError());
             chains(1, stream);
-            hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, side, WP_VP8L_SIDE_DELAY_US);
+            hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, side, delay_us);
             chains(2, side);
             if (hipEventRecord(g_join[dev], side) != hipSuccess || hipStreamWaitEvent(stream, g_join[dev], 0) != hipSuccess) return int(hipGetLastError());
         } else {
