@@ -9,9 +9,14 @@ from webp_amd import parse
 from webp_amd._lib import Vp8lFrame, check, lib
 from webp_amd.decoder import LosslessBatch
 
+pattern = "lossless1080_*.webp"
+if "--pattern" in sys.argv:           # other streams of bench_data/: python tools/lossless_times.py 1024 --pattern "ll1080_mixed_*.webp"
+    k = sys.argv.index("--pattern")
+    pattern = sys.argv[k + 1]
+    del sys.argv[k:k + 2]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-paths = sorted(glob.glob(os.path.join(root, "bench_data", "lossless1080_*.webp")))
+paths = sorted(glob.glob(os.path.join(root, "bench_data", pattern)))
 if len(sys.argv) > 2:                # one of the streams only: python tools/lossless_times.py 1024 <index>
     paths = [paths[int(sys.argv[2])]]
 files = [parse(open(p, "rb").read()) for p in paths]

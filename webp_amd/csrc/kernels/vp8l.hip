@@ -617,35 +617,44 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                     const bool chain = is_l || use_b || m == 6 || m == 7;
                     const bool any11 = __builtin_amdgcn_ballot_w64(m == 11) != 0, any12 = __builtin_amdgcn_ballot_w64(m == 12) != 0,
                                any13 = __builtin_amdgcn_ballot_w64(m == 13) != 0;
-                    uint32_t A[4], B[4], N[4], TLv[4];
+                    // modes 0..10 (constants, single neighbours and the averages): skipped as a whole when no lane has one --
+                    // libwebp's photo-like streams mix select (11) and clamp-add-subtract (12) tile by tile and little else
+                    const bool any_low = __builtin_amdgcn_ballot_w64(m <= 10) != 0;
+                    uint32_t A[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0}, N[4] = {0, 0, 0, 0}, TLv[4];
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const int j = 4 * g4 + jj, x = xg + jj;
-                        const uint32_t T = T4[j];
-                        const uint32_t TL = j ? T4[j - 1] : TLfirst;
-                        uint32_t TR = j < kPC - 1 ? T4[j + 1] : tr_last;
-                        if (x == w - 1) TR = first_px;                        // linear addressing: top+4 is the row's own first pixel
-                        const uint32_t aTTR = avg_px(T, TR);
-                        TLv[jj] = TL;
-                        A[jj] = m5 ? TR : (m == 7 ? T : TL);
-                        B[jj] = m5 ? T : aTTR;
-                        uint32_t n = 0u;                                      // modes 14, 15: nothing is added
-                        n = m == 0 ? 0xff000000u : n;
-                        n = m == 2 ? T : n;
-                        n = m == 3 ? TR : n;
-                        n = m == 4 ? TL : n;
-                        n = m == 8 ? avg_px(TL, T) : n;
-                        n = m == 9 ? aTTR : n;
-                        N[jj] = n;
+                    for (int jj = 0; jj < 4; ++jj) TLv[jj] = (4 * g4 + jj) ? T4[4 * g4 + jj - 1] : TLfirst;
+                    if (any_low) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int j = 4 * g4 + jj, x = xg + jj;
+                            const uint32_t T = T4[j];
+                            const uint32_t TL = TLv[jj];
+                            uint32_t TR = j < kPC - 1 ? T4[j + 1] : tr_last;
+                            if (x == w - 1) TR = first_px;                        // linear addressing: top+4 is the row's own first pixel
+                            const uint32_t aTTR = avg_px(T, TR);
+                            A[jj] = m5 ? TR : (m == 7 ? T : TL);
+                            B[jj] = m5 ? T : aTTR;
+                            uint32_t n = 0u;                                      // modes 14, 15: nothing is added
+                            n = m == 0 ? 0xff000000u : n;
+                            n = m == 2 ? T : n;
+                            n = m == 3 ? TR : n;
+                            n = m == 4 ? TL : n;
+                            n = m == 8 ? avg_px(TL, T) : n;
+                            n = m == 9 ? aTTR : n;
+                            N[jj] = n;
+                        }
                     }
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
                         const int j = 4 * g4 + jj, x = xg + jj;
                         const uint32_t L = Lpx, T = T4[j];
-                        const uint32_t X = avg_px(L, A[jj]);
-                        uint32_t pr = use_b ? avg_px(X, B[jj]) : X;
-                        pr = is_l ? L : pr;
-                        pr = chain ? pr : N[jj];
+                        uint32_t pr = 0u;
+                        if (any_low) {
+                            const uint32_t X = avg_px(L, A[jj]);
+                            pr = use_b ? avg_px(X, B[jj]) : X;
+                            pr = is_l ? L : pr;
+                            pr = chain ? pr : N[jj];
+                        }
                         if (any11) {     // select: l = sum|TL - T|, t = sum|TL - L|; L if l < t else T
                             const uint32_t l = __builtin_amdgcn_sad_u8(TLv[jj], T, 0u), t = __builtin_amdgcn_sad_u8(TLv[jj], L, 0u);
                             pr = m == 11 ? (l < t ? L : T) : pr;
