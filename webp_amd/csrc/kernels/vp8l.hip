@@ -244,9 +244,10 @@ __device__ __forceinline__ uint32_t predict_px(int mode, uint32_t L, uint32_t T,
         return l < t ? L : T; }
     // the two clamped modes work on the channel pairs (0,2) and (1,3) in packed 16-bit arithmetic
     case 12: {   // clampAddSubtractFull(L, T, TL) per channel
-        const short2_t e = as_s2(L & 0x00ff00ffu) + as_s2(T & 0x00ff00ffu) - as_s2(TL & 0x00ff00ffu);
-        const short2_t o = as_s2((L >> 8) & 0x00ff00ffu) + as_s2((T >> 8) & 0x00ff00ffu) - as_s2((TL >> 8) & 0x00ff00ffu);
-        return clip_pack(e, o); }
+        // (T - TL first: it does not depend on L, the pixel-to-pixel chain)
+        const short2_t de = as_s2(T & 0x00ff00ffu) - as_s2(TL & 0x00ff00ffu);
+        const short2_t dO = as_s2((T >> 8) & 0x00ff00ffu) - as_s2((TL >> 8) & 0x00ff00ffu);
+        return clip_pack(as_s2(L & 0x00ff00ffu) + de, as_s2((L >> 8) & 0x00ff00ffu) + dO); }
     case 13: {   // clampAddSubtractHalf(avg2(L, T), TL): a + trunc((a - b) / 2)  (Q10: C-style division, rounds towards zero)
         const uint32_t av = avg_px(L, T);
         const short2_t ae = as_s2(av & 0x00ff00ffu), ao = as_s2((av >> 8) & 0x00ff00ffu);
