@@ -1,5 +1,7 @@
 """The other BASELINE.json configurations, timed inside the driver-captured bench.py line (`"secondary": [...]`):
   cfg 3  1024 x 1920x1080 VP8L lossless: inverse transform chain + RGBA->ARGB on device-resident decodePix output
+  cfg 3b the same on photo-like streams whose tiles mix predictor modes (not a BASELINE configuration: cfg 3's noise images
+         use one mode throughout, which is the predictor pass's best case)
   cfg 4  animated WebP, 300 x 1280x720 lossy frames with VP8L-coded ALPH planes (a real ANMF file, tools/make_anim.py)
   cfg 5  this GPU's share of 8192 x 3840x2160 lossy over 8 GPUs: 1024 x 4K, the same pipeline as the headline
   e2e    1024 x 1080p lossy, file bytes in host memory -> ARGB + planes in pinned host memory (LossyStream)
@@ -35,14 +37,15 @@ def _record(name, workload, ms, px, alg_bytes, verified, **extra):
     return r
 
 
-def lossless(device, n=1024, reps=4):
+def lossless(device, n=1024, reps=4, pattern="lossless1080_*.webp", name="cfg3_lossless_1080p",
+             what="predictor + cross-colour + subtract-green, and a palette image"):
     import numpy as np
     import torch
     from oracle import oracle
     from webp_amd import parse
     from webp_amd._lib import check, lib
     from webp_amd.decoder import LosslessBatch
-    paths = sorted(glob.glob(os.path.join(ROOT, "bench_data", "lossless1080_*.webp")))
+    paths = sorted(glob.glob(os.path.join(ROOT, "bench_data", pattern)))
     datas = [open(p, "rb").read() for p in paths]
     files = [parse(d) for d in datas]
     b = LosslessBatch([files[i % len(files)].frames[0] for i in range(n)])
@@ -70,8 +73,15 @@ def lossless(device, n=1024, reps=4):
         if not np.array_equal(got, want[i % len(files)]):
             raise RuntimeError("lossless frame %d differs from the oracle" % i)
     px = sum(b.desc[i].width * b.desc[i].height for i in range(n))
-    return _record("cfg3_lossless_1080p", "%d x 1920x1080 VP8L (%d libwebp streams cycled: predictor + cross-colour + subtract-green, and a palette image): inverse chain + ARGB"
-                   % (n, len(files)), ms, px, b.pix.size + b.aux.size + 4 * px, len(idx))
+    return _record(name, "%d x 1920x1080 VP8L (%d libwebp streams cycled: %s): inverse chain + ARGB"
+                   % (n, len(files), what), ms, px, b.pix.size + b.aux.size + 4 * px, len(idx))
+
+
+def lossless_mixed(device):
+    """cfg 3's shape on photo-like streams (tools/make_mixed_lossless.py): libwebp mixes predictor modes tile by tile there
+    (select and clamp-add-subtract), so the wavefronts of the predictor pass hold several modes at once."""
+    return lossless(device, pattern="ll1080_mixed_m*.webp", name="cfg3b_lossless_1080p_mixed_modes",
+                    what="photo-like image, methods 4 and 6: predictor with select / clamp-add-subtract mixed tile by tile + cross-colour")
 
 
 def anim_alpha(device, n=300, reps=4):
@@ -262,7 +272,7 @@ def run_all(device):
     import gc
     import torch
     out = []
-    for fn in (lossless, anim_alpha, lossy_4k, vp8l_resolve, end_to_end):
+    for fn in (lossless, lossless_mixed, anim_alpha, lossy_4k, vp8l_resolve, end_to_end):
         t0 = time.time()
         try:
             rec = fn(device)
