@@ -139,7 +139,15 @@ void vp8l_color_indexing_kernel(const wp_vp8l_frame* __restrict__ frames, int pa
     const Loc loc = locate(fr, idx);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(loc.in_tmp ? tmp + fr.tmp_off : pix + fr.pix_off);
     const int w = fr.t[idx].old_width, bits = fr.t[idx].bits;
-    const uint32_t* palette = reinterpret_cast<const uint32_t*>(aux + fr.t[idx].data_off);
+    // The palette (1 << (8 >> bits) entries: 256, 16, 4 or 2) goes to LDS: a gather from memory per pixel is a request to
+    // the L1 per pixel, and the L1's request rate is what this pass and whatever runs beside it are bound by.
+    __shared__ uint32_t palette[256];
+    {
+        const uint32_t* gpal = reinterpret_cast<const uint32_t*>(aux + fr.t[idx].data_off);
+        const int n_pal = 1 << (8 >> bits);
+        for (int k = threadIdx.x; k < n_pal; k += blockDim.x) palette[k] = gpal[k];
+        __syncthreads();
+    }
     const bool final_out = idx == 0 && output_writer(fr, swizzle) == kOutIndexing;      // the last transform undone: straight into the result slab
     const int sw = final_out ? swizzle : WP_SWIZZLE_NONE;
     const bool green = sw == WP_SWIZZLE_GREEN;                              // one byte per pixel out
@@ -166,11 +174,15 @@ void vp8l_color_indexing_kernel(const wp_vp8l_frame* __restrict__ frames, int pa
     for (; i < total; i += stride) {
         const int x0 = 4 * xq;
         const uint32_t* srow = src + y * pw;
+        // the four pixels share one packed source dword (bits 2, 3) or two (bits 1): each is loaded once
+        const int d0 = x0 >> bits;
+        const uint32_t s0 = (srow[d0] >> 8) & 0xff;
+        const uint32_t s1 = bits == 1 ? (srow[min(d0 + 1, pw - 1)] >> 8) & 0xff : s0;
         uint32_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int x = min(x0 + j, w - 1);
-            const uint32_t g = (srow[x >> bits] >> 8) & 0xff;
+            const int x = x0 + j;                    // (pixels past the row's end are computed from what was loaded and not stored)
+            const uint32_t g = ((x >> bits) == d0) ? s0 : s1;
             o[j] = swizzled(palette[(g >> ((x & xmask) * bpp)) & vmask], green ? WP_SWIZZLE_NONE : sw);
         }
         if (green) {
