@@ -46,9 +46,16 @@ void vp8l_resolve_kernel(const wp_vp8l_tokens_frame* __restrict__ frames, const 
     for (uint32_t i = lane; i < cc_size; i += 64) { cval[i] = 0; cown[i] = 0; }
 
     uint32_t pos = 0, p = 0, cached = 0;
+    // (settle: the wait for a token block's load sits where the block is loaded.  Left to the compiler it sits in front of
+    // every token's v_readlane, as s_waitcnt vmcnt(0) -- which also waits for every pixel store of the token before.)
     uint32_t blk_base = 0, blk = lane < n_words ? tok[lane] : 0u;
+    asm volatile("; settle %0" : "+v"(blk));
     while (pos < n_words && p < total) {
-        if (pos - blk_base >= 64u) { blk_base = pos; blk = (lane < n_words - pos) ? tok[pos + lane] : 0u; }
+        if (pos - blk_base >= 64u) {
+            blk_base = pos;
+            blk = (lane < n_words - pos) ? tok[pos + lane] : 0u;
+            asm volatile("; settle %0" : "+v"(blk));
+        }
         const uint32_t t = lane_word(blk, pos - blk_base);
         const uint32_t kind = t >> 30, arg = t & 0x3fffffffu;
         if (kind == WP_TOK_LITERALS) {
@@ -58,7 +65,17 @@ void vp8l_resolve_kernel(const wp_vp8l_tokens_frame* __restrict__ frames, const 
                 const uint32_t w = uint32_t(__builtin_amdgcn_ds_bpermute(int(4u * (first - blk_base + lane)), int(blk)));
                 if (lane < n) { ring[(p + lane) & kRingMask] = w; out[p + lane] = w; }
             } else {
-                for (uint32_t c = 0; c < n; c += 64) {
+                // a long run (an image that does not compress is one literal per pixel): four loads in flight per round --
+                // with one, a round is a trip to memory
+                uint32_t c = 0;
+                for (; c + 256 <= n; c += 256) {
+                    uint32_t w[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) w[k] = tok[first + c + 64 * k + lane];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const uint32_t i = c + 64 * k + lane; ring[(p + i) & kRingMask] = w[k]; out[p + i] = w[k]; }
+                }
+                for (; c < n; c += 64) {
                     const uint32_t i = c + lane;
                     if (i < n) { const uint32_t w = tok[first + i]; ring[(p + i) & kRingMask] = w; out[p + i] = w; }
                 }
@@ -77,12 +94,41 @@ void vp8l_resolve_kernel(const wp_vp8l_tokens_frame* __restrict__ frames, const 
                 const uint32_t src0 = p - dist;
                 const bool periodic = dist < l;
                 if (dist <= kRingReach) {
-                    for (uint32_t c = 0; c < l; c += 64) {
-                        const uint32_t i = c + lane;
-                        if (i < l) {
-                            const uint32_t w = ring[(src0 + (periodic ? i % dist : i)) & kRingMask];
-                            ring[(p + i) & kRingMask] = w;
-                            out[p + i] = w;
+                    // Source and destination never overlap inside a piece (dist >= l, or -- periodic -- every source lies in
+                    // the `dist` pixels before p).  Pixel i of a periodic copy reads source i mod dist: lane mod dist by a
+                    // float reciprocal with one correction step (lane < 64, dist < 4096: exact), advanced by 64 mod dist per
+                    // round, no integer division anywhere.
+                    uint32_t r = lane;
+                    uint32_t step = 64u;
+                    if (periodic) {
+                        const float inv = __builtin_amdgcn_rcpf(float(dist));
+                        r = lane - uint32_t(float(lane) * inv) * dist;
+                        if (int(r) < 0) r += dist;
+                        if (r >= dist) r -= dist;
+                        step = 64u - uint32_t(64.0f * inv) * dist;      // uniform
+                        if (int(step) < 0) step += dist;
+                        if (step >= dist) step -= dist;
+                    }
+                    if (l <= 64u) {                          // most copies: one round
+                        if (lane < l) {
+                            const uint32_t w = ring[(src0 + r) & kRingMask];
+                            ring[(p + lane) & kRingMask] = w;
+                            out[p + lane] = w;
+                        }
+                    } else {                                 // four reads in flight before their four writes
+                        for (uint32_t c = 0; c < l; c += 256) {
+                            uint32_t w[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                w[k] = (c + 64 * k + lane < l) ? ring[(src0 + r) & kRingMask] : 0u;
+                                r += step;
+                                if (periodic && r >= dist) r -= dist;
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const uint32_t i = c + 64 * k + lane;
+                                if (i < l) { ring[(p + i) & kRingMask] = w[k]; out[p + i] = w[k]; }
+                            }
                         }
                     }
                 } else {                                     // dist > kRingReach > l: plain forward copy out of the slab
@@ -111,14 +157,20 @@ void vp8l_resolve_kernel(const wp_vp8l_tokens_frame* __restrict__ frames, const 
                     if (active) w = ring[idx & kRingMask];
                 } else {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    if (active) w = far_load(out + idx);
+                    uint32_t wf = 0;
+                    if (active) wf = far_load(out + idx);
+                    asm volatile("; settle %0" : "+v"(wf));       // (see above: keeps s_waitcnt vmcnt(0) out of the common path)
+                    w = wf;
                 }
                 const uint32_t key = cache_hash(w) >> cc_shift;
-                if (active) atomicMax(&cown[key], idx + 1);
-                if (active && *static_cast<volatile uint32_t*>(&cown[key]) == idx + 1) cval[key] = w;
+                // (workgroup-scope relaxed atomics: LDS operations of one wavefront execute in order; the default
+                // atomics would drain the wavefront's pixel stores first)
+                if (active) __hip_atomic_fetch_max(&cown[key], idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (active && __hip_atomic_load(&cown[key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == idx + 1)
+                    __hip_atomic_store(&cval[key], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             cached = p;
-            const uint32_t w = *static_cast<volatile uint32_t*>(&cval[arg]);
+            const uint32_t w = __hip_atomic_load(&cval[arg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (lane == 0) { ring[p & kRingMask] = w; out[p] = w; }
             p += 1;
             pos += 1;
