@@ -684,9 +684,14 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                     if (to_out) {            // final pixels: R += G, B += G if a subtract-green follows, then the byte order asked for
                         uint32_t fin[kPC];
 #pragma unroll
-                        for (int j = 0; j < kPC; ++j) {
-                            const uint32_t g = (res[j] >> 8) & 0xff;
-                            fin[j] = swizzled(sg_out ? add_px(res[j], g | (g << 16)) : res[j], swizzle);
+                        for (int j = 0; j < kPC; ++j) fin[j] = res[j];
+                        if (sg_out) {            // (wavefront-uniform branches, not a select per pixel)
+#pragma unroll
+                            for (int j = 0; j < kPC; ++j) { const uint32_t g = (res[j] >> 8) & 0xff; fin[j] = add_px(res[j], g | (g << 16)); }
+                        }
+                        if (swizzle == WP_SWIZZLE_ARGB) {
+#pragma unroll
+                            for (int j = 0; j < kPC; ++j) fin[j] = (fin[j] << 8) | (fin[j] >> 24);
                         }
 #ifndef WP_PRED_NO_STAGE
                         uint32_t* st = &stage[wave][r][(k & 3) * kPC];
