@@ -274,6 +274,19 @@ __device__ __forceinline__ uint32_t predict_px(int mode, uint32_t L, uint32_t T,
 __device__ __forceinline__ uint32_t from_lane_above(uint32_t v) {
     return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x138, 0xf, 0xf, true));
 }
+// ... with lane 0 keeping `old` (the band's first row takes the row above the band from memory instead)
+__device__ __forceinline__ uint32_t from_lane_above_or(uint32_t old, uint32_t v) {
+    return uint32_t(__builtin_amdgcn_update_dpp(int(old), int(v), 0x138, 0xf, 0xf, false));
+}
+// value of lane r + J of the same 16-lane row (row_shl:J); J = 0: the lane's own
+template <int J> __device__ __forceinline__ uint32_t from_lane_plus(uint32_t v) {
+    if constexpr (J == 0) return v;
+    else return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x100 + J, 0xf, 0xf, true));
+}
+template <int N, int... J>
+__device__ __forceinline__ void rows_above(uint32_t (&T)[N], const uint32_t (&P)[N], uint32_t an, std::integer_sequence<int, J...>) {
+    ((T[J] = from_lane_above_or(from_lane_plus<J>(an), P[J])), ...);
+}
 constexpr uint32_t kPredSeqShift = 15;      // progress word = (band sequence << 15) | pixels finished in the band's last row
 constexpr int kPredRows = 64;
 // Wavefronts per workgroup (= bands of one frame that can be in flight).  A band trails the one above by 64 steps and
@@ -537,18 +550,13 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                 }
                 if (c == n_steps) break;
                 // ---- chunk k of the row above: lane r-1's previous outputs, or memory for the band's first row
-#pragma unroll
-                for (int j = 0; j < kPC; ++j) T4[j] = from_lane_above(P1[j]);
-                uint32_t tr_mem = 0;
+                // (an_v: pixel kPC * c + lane of the row above the band in lanes 0..kPC, loaded a step ago: lane 0 takes pixel j
+                // from lane j with one DPP move, every other lane its T from the lane above with another)
+                uint32_t an_now = 0;
+                if (has_above) asm volatile("v_mov_b32 %0, %1" : "=v"(an_now) : "v"(an_v));
+                rows_above(T4, P1, an_now, std::make_integer_sequence<int, kPC>());
+                const uint32_t tr_mem = from_lane_plus<kPC>(an_now);
                 if (has_above) {
-                    uint32_t an_now;
-                    asm volatile("v_mov_b32 %0, %1" : "=v"(an_now) : "v"(an_v));
-#pragma unroll
-                    for (int j = 0; j < kPC; ++j) {
-                        const uint32_t a = uint32_t(__builtin_amdgcn_readlane(int(an_now), j));
-                        T4[j] = r == 0 ? a : T4[j];
-                    }
-                    tr_mem = uint32_t(__builtin_amdgcn_readlane(int(an_now), kPC));
                     if (c + 1 < n_chunks) {
                         // lane 0 is about to read pixels up to kPC*(c+2) of the row above the band
                         wait_above(uint32_t(min(kPC * (c + 2) + 1, w)));
@@ -577,8 +585,7 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                 for (int g4 = 0; g4 < kPC / 4; ++g4) {
                     if (g4 == 1) {
                         // the row above has just produced the pixel that is TR of this chunk's last pixel (every lane takes part)
-                        const uint32_t tr_shfl = from_lane_above(res[0]);
-                        tr_last = (has_above && r == 0) ? tr_mem : tr_shfl;
+                        tr_last = from_lane_above_or(tr_mem, res[0]);
                     }
                     if (!act) continue;
                     if (cc) {                // inverseCrossColor of the pixels loaded (a 4-pixel group never straddles a tile: bits >= 2)
