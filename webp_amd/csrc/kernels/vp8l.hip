@@ -467,11 +467,10 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                 int mode_of[kPC / 4];
                 // (real moves, hidden from the register coalescer: left to itself it loads the next step's inputs into fresh
                 // registers and moves them over at the END of this step, behind an s_waitcnt vmcnt(0) that undoes the prefetch)
+                const unsigned long long odd = __builtin_amdgcn_ballot_w64((k & 1) != 0);
 #pragma unroll
-                for (int j = 0; j < kPC; ++j) {
-                    const uint32_t mine = (k & 1) ? nx_in2[j] : nx_in[j];     // the pair's first or second chunk
-                    asm volatile("v_mov_b32 %0, %1" : "=v"(in[j]) : "v"(mine));
-                }
+                for (int j = 0; j < kPC; ++j)                                   // the pair's first or second chunk
+                    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(in[j]) : "v"(nx_in[j]), "v"(nx_in2[j]), "s"(odd));
 #pragma unroll
                 for (int g4 = 0; g4 < kPC / 4; ++g4) {
                     uint32_t m_;
