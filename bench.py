@@ -106,8 +106,8 @@ def verify_outputs(db, batch, paths, n_images):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--images", type=int, default=1024, help="images per GPU (BASELINE.json configs[1]: 1024; 4096 = 8 frames per persistent "
                     "workgroup gives every wavefront the same number of bands and is ~10 %% faster per image)")
     ap.add_argument("--pattern", default="lossy1080_*.webp")
