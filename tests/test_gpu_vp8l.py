@@ -65,6 +65,37 @@ def test_predictor_all_modes(bits):
         assert np.array_equal(g, e), (c["width"], c["height"])
 
 
+@pytest.mark.parametrize("swizzle", [0, 1])
+def test_predictor_one_or_two_modes_per_image(swizzle):
+    """The predictor's fast paths: every lane of a wavefront with the same mode (each of the 16, the ones that read TR
+    included), or select and clamp-add-subtract mixed tile by tile -- widths that end on a full group, in mid-group and
+    mid-chunk, more than one band, with and without a cross-colour before the predictor (fused into its loads)."""
+    from oracle import oracle
+    rng = np.random.default_rng(4100 + swizzle)
+    cases, want = [], []
+    for (w, h) in [(64, 70), (67, 130), (129, 66), (40, 200), (200, 65)]:
+        for modes in [[m] for m in range(16)] + [[11, 12], [10, 11]]:
+            bits = int(rng.integers(2, 5))
+            pix = rng.integers(0, 256, 4 * w * h, dtype=np.uint8)
+            if rng.integers(0, 2):
+                pix = (pix // 32).astype(np.uint8)
+            t = _tiles(rng, w, h, bits, modes)
+            tr = [(0, bits, w, t)]
+            e = oracle.inverse_predictor(w, bits, t, pix, h)
+            if rng.integers(0, 2):            # [predictor, cross-colour] in the bitstream: cross-colour is undone first
+                cb = int(rng.integers(2, 5))
+                ct = _tiles(rng, w, h, cb)
+                tr = [(0, bits, w, t), (1, cb, w, ct)]
+                e = oracle.inverse_predictor(w, bits, t, oracle.inverse_cross_color(w, cb, ct, pix, h), h)
+            cases.append(dict(width=w, height=h, coded_width=w, pix=pix, transforms=tr))
+            if swizzle == 1:
+                e = np.ascontiguousarray(e.reshape(-1, 4)[:, [3, 0, 1, 2]]).reshape(-1)
+            want.append(e)
+    got = _run_chain(cases, swizzle=swizzle)
+    for c, g, e in zip(cases, got, want):
+        assert np.array_equal(g, e), (c["width"], c["height"], [t[:2] for t in c["transforms"]])
+
+
 def test_cross_color_and_subtract_green():
     from oracle import oracle
     rng = np.random.default_rng(5)

@@ -79,9 +79,11 @@ def lossless(device, n=1024, reps=4, pattern="lossless1080_*.webp", name="cfg3_l
 
 def lossless_mixed(device):
     """cfg 3's shape on photo-like streams (tools/make_mixed_lossless.py): libwebp mixes predictor modes tile by tile there
-    (select and clamp-add-subtract), so the wavefronts of the predictor pass hold several modes at once."""
-    return lossless(device, pattern="ll1080_mixed_m*.webp", name="cfg3b_lossless_1080p_mixed_modes",
-                    what="photo-like image, methods 4 and 6: predictor with select / clamp-add-subtract mixed tile by tile + cross-colour")
+    (select and clamp-add-subtract; or mode 10 with a sprinkling of 7 and 8), so the wavefronts of the predictor pass hold several
+    modes at once."""
+    return lossless(device, pattern="ll1080_*_m*.webp", name="cfg3b_lossless_1080p_mixed_modes",
+                    what="photo-like image at methods 4 and 6: predictor with select / clamp-add-subtract mixed tile by tile; smooth image: "
+                         "mode 10 with a few tiles of 7 and 8; all with cross-colour")
 
 
 def anim_alpha(device, n=300, reps=4):

@@ -1,6 +1,7 @@
 """Generates bench_data/ll1080_mixed_m{4,6}.webp with PIL's libwebp: a photo-like 1080p image (smooth waves, flat
 patches with hard edges, 4x4-blocky texture) whose lossless encoding mixes predictor modes per tile (select and
-clamp-add-subtract about half each), unlike the noise images of cfg 3 whose tiles all use select.  Used by
+clamp-add-subtract about half each), unlike the noise images of cfg 3 whose tiles all use select; and
+bench_data/ll1080_smooth_m4.webp, a smooth image whose tiles nearly all use mode 10 (reads TR).  Used by
 tools/lossless_times.py --pattern to time the predictor's mixed-mode path; not part of bench.py's cfg 3."""
 import io, os
 import numpy as np
@@ -21,3 +22,10 @@ for m in (4, 6):
     Image.fromarray(img).save(b, "WEBP", lossless=True, method=m, quality=75)
     open(os.path.join(OUT, "ll1080_mixed_m%d.webp" % m), "wb").write(b.getvalue())
     print("ll1080_mixed_m%d.webp" % m, len(b.getvalue()))
+# a smooth image with fine noise (sky-like): libwebp takes mode 10 (average of averages, reads TR) for nearly every tile
+rng = np.random.default_rng(1)
+sm = np.clip(np.stack([xx / 7.5 + yy / 13.5, 200 - yy / 6.0, 120 + np.sin(xx / 50.0) * 60], -1) + rng.normal(0, 2, (H, W, 3)), 0, 255).astype(np.uint8)
+b = io.BytesIO()
+Image.fromarray(sm).save(b, "WEBP", lossless=True, method=4, quality=75)
+open(os.path.join(OUT, "ll1080_smooth_m4.webp"), "wb").write(b.getvalue())
+print("ll1080_smooth_m4.webp", len(b.getvalue()))

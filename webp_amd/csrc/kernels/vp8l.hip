@@ -601,33 +601,39 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                     {
                         const int m0 = __builtin_amdgcn_readfirstlane(m);
                         const bool inside = y > 0 && xg > 0 && xg + 4 <= w;
-                        const bool plain = m == m0 && inside;
                         constexpr uint32_t kNoTR = 0xF9D7u;       // modes 0,1,2,4,6,7,8,11,12,13,14,15
+                        // (the modes that read TR -- 3, 5, 9, 10; libwebp likes 10 for smooth and for fractal-like images -- also
+                        // keep away from the row's last pixel, whose TR is the row's own first pixel)
+                        const bool plain = m == m0 && inside && (((kNoTR >> m0) & 1u) || xg + 4 < w);
                         auto run4 = [&](auto pred) __attribute__((always_inline)) {
                             uint32_t L = Lpx;
 #pragma unroll
                             for (int jj = 0; jj < 4; ++jj) {
                                 const int j = 4 * g4 + jj;
-                                L = add_px(in[j], pred(L, T4[j], j ? T4[j - 1] : TLfirst));
+                                L = add_px(in[j], pred(L, T4[j], j ? T4[j - 1] : TLfirst, j < kPC - 1 ? T4[j + 1] : tr_last));
                                 res[j] = L;
                             }
                             Lpx = L;
                         };
-                        if (__builtin_amdgcn_ballot_w64(!plain) == 0 && ((kNoTR >> m0) & 1u)) {
+                        if (__builtin_amdgcn_ballot_w64(!plain) == 0) {
                             // (the switch sits outside the pixel loop: one branch sequence per group, not per pixel)
                             switch (m0) {
-                            case 0: run4([](uint32_t, uint32_t, uint32_t) { return 0xff000000u; }); break;
-                            case 1: run4([](uint32_t L, uint32_t, uint32_t) { return L; }); break;
-                            case 2: run4([](uint32_t, uint32_t T, uint32_t) { return T; }); break;
-                            case 4: run4([](uint32_t, uint32_t, uint32_t TL) { return TL; }); break;
-                            case 6: run4([](uint32_t L, uint32_t, uint32_t TL) { return avg_px(L, TL); }); break;
-                            case 7: run4([](uint32_t L, uint32_t T, uint32_t) { return avg_px(L, T); }); break;
-                            case 8: run4([](uint32_t, uint32_t T, uint32_t TL) { return avg_px(TL, T); }); break;
-                            case 11: run4([](uint32_t L, uint32_t T, uint32_t TL) {
+                            case 0: run4([](uint32_t, uint32_t, uint32_t, uint32_t) { return 0xff000000u; }); break;
+                            case 1: run4([](uint32_t L, uint32_t, uint32_t, uint32_t) { return L; }); break;
+                            case 2: run4([](uint32_t, uint32_t T, uint32_t, uint32_t) { return T; }); break;
+                            case 3: run4([](uint32_t, uint32_t, uint32_t, uint32_t TR) { return TR; }); break;
+                            case 4: run4([](uint32_t, uint32_t, uint32_t TL, uint32_t) { return TL; }); break;
+                            case 5: run4([](uint32_t L, uint32_t T, uint32_t, uint32_t TR) { return avg_px(avg_px(L, TR), T); }); break;
+                            case 6: run4([](uint32_t L, uint32_t, uint32_t TL, uint32_t) { return avg_px(L, TL); }); break;
+                            case 7: run4([](uint32_t L, uint32_t T, uint32_t, uint32_t) { return avg_px(L, T); }); break;
+                            case 8: run4([](uint32_t, uint32_t T, uint32_t TL, uint32_t) { return avg_px(TL, T); }); break;
+                            case 9: run4([](uint32_t, uint32_t T, uint32_t, uint32_t TR) { return avg_px(T, TR); }); break;
+                            case 10: run4([](uint32_t L, uint32_t T, uint32_t TL, uint32_t TR) { return avg_px(avg_px(L, TL), avg_px(T, TR)); }); break;
+                            case 11: run4([](uint32_t L, uint32_t T, uint32_t TL, uint32_t) {
                                     return __builtin_amdgcn_sad_u8(TL, T, 0u) < __builtin_amdgcn_sad_u8(TL, L, 0u) ? L : T; }); break;
-                            case 12: run4([](uint32_t L, uint32_t T, uint32_t TL) { return predict_px(12, L, T, TL, 0u); }); break;
-                            case 13: run4([](uint32_t L, uint32_t T, uint32_t TL) { return predict_px(13, L, T, TL, 0u); }); break;
-                            default: run4([](uint32_t, uint32_t, uint32_t) { return 0u; }); break;      // 14, 15: nothing is added
+                            case 12: run4([](uint32_t L, uint32_t T, uint32_t TL, uint32_t) { return predict_px(12, L, T, TL, 0u); }); break;
+                            case 13: run4([](uint32_t L, uint32_t T, uint32_t TL, uint32_t) { return predict_px(13, L, T, TL, 0u); }); break;
+                            default: run4([](uint32_t, uint32_t, uint32_t, uint32_t) { return 0u; }); break;      // 14, 15: nothing is added
                             }
                             continue;
                         }
@@ -635,7 +641,7 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                         // computed and one is taken per lane: 21 instructions per pixel where the general code takes 30.
                         if (__builtin_amdgcn_ballot_w64(!(inside && (m == 11 || m == 12))) == 0) {      // (not all the same: that was the case above)
                             const bool is12 = m == 12;
-                            run4([&](uint32_t L, uint32_t T, uint32_t TL) {
+                            run4([&](uint32_t L, uint32_t T, uint32_t TL, uint32_t) {
                                 const uint32_t sel = __builtin_amdgcn_sad_u8(TL, T, 0u) < __builtin_amdgcn_sad_u8(TL, L, 0u) ? L : T;
                                 return is12 ? predict_px(12, L, T, TL, 0u) : sel; });
                             continue;
