@@ -11,8 +11,11 @@ instead (each kernel alone on the GPU); `--alone` adds the single-stream figure 
 Metric: decoded Mpix/s, counting visible pixels, whole job over all GPUs.
 
   python bench.py --gpus N --steps K --warmup W [--images 1024]
-  N > 1: launched by torch.distributed.run, one rank per GPU; the batch is sharded by image index with
-  no data-path collective (weak scaling: every rank decodes its own `--images` images).
+  N > 1: one rank per GPU; the batch is sharded by image index with no data-path collective (weak scaling: every rank
+  decodes its own `--images` images; `--total-images M` shards ONE batch of M images instead: cfg 5 is
+  `--gpus 8 --total-images 8192 --pattern lossy2160_q75_0.webp`).  Under torch.distributed.run (WORLD_SIZE set) this
+  process is one rank and --gpus must equal the world size; started plainly with --gpus N > 1 it launches the N ranks
+  itself as child processes (launch_ranks) and relays rank 0's line.
 """
 import argparse
 import glob
@@ -103,6 +106,38 @@ def verify_outputs(db, batch, paths, n_images):
     return {"count": len(idx), "indices": idx, "against": "oracle.decode (planes + ARGB, bit-exact)"}
 
 
+def launch_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes the launcher.  It
+    starts N rank processes (one per GPU) as CHILDREN through torch.distributed.run -- before anything here has touched the
+    GPU, and never by replacing this process -- relays rank 0's JSON line and returns the job's exit status (non-zero if
+    any rank failed).  WEBP_BENCH_RANK_SCRIPT names the per-rank program (default: this file; tests/ substitutes a stub so
+    that the launcher can be exercised without GPUs)."""
+    import socket
+    import subprocess
+    script = os.environ.get("WEBP_BENCH_RANK_SCRIPT") or os.path.abspath(__file__)
+    if not os.environ.get("WEBP_BENCH_RANK_SCRIPT"):
+        import torch                                  # device_count() does not initialise the GPU on this image
+        have = torch.cuda.device_count()
+        if have < n_gpus:
+            sys.stderr.write("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing to run (a smaller run would be "
+                             "reported under the wrong n_gpus)\n" % (n_gpus, have))
+            return 2
+    with socket.socket() as s:                        # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write("bench.py: the %d-rank job failed (exit status %d%s)\n" % (n_gpus, proc.returncode, "" if lines else ", no JSON line from rank 0"))
+        return proc.returncode or 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +158,17 @@ def main():
     ap.add_argument("--alone", action="store_true", help="after the timed region also time the single-stream fused call (config.serial_ms_per_step)")
     args = ap.parse_args()
     args.one_launch = not args.two_phase             # default: vp8_mb_kernel (reconstruction + loop filter, one kernel) with the finishing pass of the step before beside it
+
+    # --gpus N is the number of ranks of the job.  Under a launcher (WORLD_SIZE set) it must agree with it; without one,
+    # N > 1 makes this process the launcher of N child ranks (nothing has touched the GPU yet).
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" in os.environ:
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks: refusing to report one as the other"
+                             % (args.gpus, os.environ["WORLD_SIZE"]))
+    elif args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
