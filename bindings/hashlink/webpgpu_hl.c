@@ -16,7 +16,7 @@ HL_PRIM int HL_NAME(device_count)(void) { return wp_device_count(); }
 HL_PRIM int HL_NAME(last_error)(vbyte* buf, int cap) { return wp_last_error((char*)buf, cap); }
 
 /* descriptors are packed by the Haxe side exactly as the C structs (little-endian, natural alignment):
- * wp_vp8_frame = 88 bytes, wp_vp8l_frame = 168 bytes, wp_alpha_frame = 32 bytes */
+ * wp_vp8_frame = 96 bytes, wp_vp8l_frame = 168 bytes, wp_alpha_frame = 32 bytes */
 HL_PRIM int HL_NAME(vp8_decode_to_argb)(int n, vbyte* frames, vbyte* mb, int n_mb, vbyte* filt, vbyte* coeff, int n_blocks,
                                         vbyte* y, vbyte* u, vbyte* v, vbyte* alpha, vbyte* argb) {
     return wp_vp8_decode_to_argb(n, (const wp_vp8_frame*)frames, (const uint32_t*)mb, (size_t)n_mb, (const uint32_t*)filt,

@@ -8,7 +8,7 @@ import haxe.io.Bytes;
     Descriptor layouts are those of include/webp_amd.h (little-endian, natural alignment).
 **/
 class Gpu {
-    public static inline final FRAME_BYTES = 88;      // sizeof(wp_vp8_frame)
+    public static inline final FRAME_BYTES = 96;      // sizeof(wp_vp8_frame)
     static var ready = false;
 
     public static function ensure():Void {
@@ -39,7 +39,8 @@ class Gpu {
         d.fill(0, FRAME_BYTES, 0);
         d.setInt32(0, width); d.setInt32(4, height); d.setInt32(8, mbw); d.setInt32(12, mbh);
         d.setInt32(16, filterType); d.setInt32(20, hasAlpha ? 1 : 0);
-        // mb_base, stile_base, cost / turn (the host-pointer entry points plan a copy), coeff_base and all offsets stay 0
+        // mb_base, stile_base, cost / turn, coeff_blocks / flags (the host-pointer entry points plan a copy and bound the frame by the
+        // coefficient count they are given), coeff_base and all offsets stay 0
         return d;
     }
 

@@ -61,7 +61,17 @@ typedef struct wp_vp8_frame {
                                  * to its persistent workgroups by slot (slot s -> workgroup s mod grid); slot i works on frame
                                  * `turn` of its launch (index relative to the launch's first frame), a permutation that pairs
                                  * heavy frames with light ones.  No counterpart in the reference (one image per call). */
+    uint32_t coeff_blocks;      /* coefficient blocks this frame owns, counted from coeff_base (valid when WP_FRAME_COEFF_BOUNDED is set) */
+    uint32_t flags;             /* WP_FRAME_*; 0 from callers that build descriptors as before */
 } wp_vp8_frame;
+/* wp_vp8_frame.flags.  WP_FRAME_COEFF_BOUNDED: coeff_blocks is valid and the device bounds every coefficient fetch of the
+ * frame by it -- a block index w[3] (+ block number) at or beyond coeff_blocks reads zeros through the hardware range
+ * check of the buffer descriptor, never memory outside the frame's own blocks.  This is how the *_dev entry points, which
+ * cannot inspect device-resident records, stay inside the slab on malformed records (the host-pointer entry points check
+ * the indices on the host and always bound the frames).  wp_vp8_batch_layout sets it.  Without the flag the device trusts
+ * w[3] (a 2 GB window from the frame's first block, as in rounds 1-2).  No counterpart in the reference, whose coeff
+ * array is per macroblock. */
+#define WP_FRAME_COEFF_BOUNDED 1u
 
 /* Per-macroblock record, 4 x uint32 (what reconstruct()'s parse half produces, Vp8Decoder.hx:772-808):
  *   w[0], w[1]  i4 MBs: predY4[j][i] as 4-bit fields, block n = 4*j+i at bits 4*(n&7) of w[n>>3]

@@ -5,7 +5,7 @@ import numpy as np
 
 
 class RawBatch:
-    def __init__(self, shapes, frames, filter_types, visible=None):
+    def __init__(self, shapes, frames, filter_types, visible=None, bounded=True):
         """shapes: [(mbw, mbh)], frames: [(mb, coeff, filt)] as make_frame returns them, filter_types: one per frame."""
         from webp_amd._lib import Vp8Frame
         n = len(frames)
@@ -19,6 +19,8 @@ class RawBatch:
             d.width, d.height = visible[i] if visible else (16 * w - (i % 5 if w > 1 else 0), 16 * h - (i % 7 if h > 1 else 0))
             d.filter_type = filter_types[i]
             d.mb_base, d.coeff_base = mb_base, cbase
+            if bounded:
+                d.coeff_blocks, d.flags = coeff.size // 16, 1      # WP_FRAME_COEFF_BOUNDED: what wp_vp8_batch_layout writes
             d.y_off, d.u_off, d.v_off, d.argb_off = yo, co, co, ao
             mb_base += w * h
             cbase += coeff.size // 16

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     from webp_amd._lib import Vp8Frame, Vp8lFrame, Vp8lTransform, AlphaFrame
-    assert ctypes.sizeof(Vp8Frame) == 88 and ctypes.sizeof(Vp8lTransform) == 32
+    assert ctypes.sizeof(Vp8Frame) == 96 and ctypes.sizeof(Vp8lTransform) == 32
     assert ctypes.sizeof(Vp8lFrame) == 16 + 4 * 32 + 24 and ctypes.sizeof(AlphaFrame) == 32
 
 
@@ -254,7 +254,7 @@ def test_header_is_plain_c99():
     """include/webp_amd.h compiles as C99 with -pedantic (what a HashLink .hdll shim or any other C binding includes)."""
     import subprocess, tempfile
     with tempfile.NamedTemporaryFile("w", suffix=".c") as f:
-        f.write('#include "webp_amd.h"\nint main(void) { return (int)sizeof(wp_vp8_frame) - 88; }\n')
+        f.write('#include "webp_amd.h"\nint main(void) { return (int)sizeof(wp_vp8_frame) - 96; }\n')
         f.flush()
         subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), f.name])
 

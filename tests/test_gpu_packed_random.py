@@ -124,6 +124,62 @@ def test_out_of_range_block_index_is_refused():
         check(lib().wp_vp8_decode_to_argb(1, desc, p(mb), 6, p(filt), p(coeff), coeff.size // 16, p(y), p(u), p(v), None, None))
 
 
+def test_device_resident_records_cannot_reach_beyond_the_frames_blocks():
+    """The *_dev entry points cannot inspect records that live in device memory.  With WP_FRAME_COEFF_BOUNDED (what
+    wp_vp8_batch_layout writes) the kernels bound every coefficient fetch of a frame by its block count, so a block index that
+    was corrupted ON THE DEVICE reads zeros -- the output equals the decode of the same records with those blocks zeroed --
+    instead of whatever lies behind the slab.  Both lossy kernels (one-kernel path and stand-alone reconstruction)."""
+    import torch
+    from oracle import oracle
+    from packed_util import RawBatch
+    from webp_amd.device import DeviceLossyBatch
+    rng = np.random.default_rng(91)
+    shapes = [(5, 4), (7, 3)]
+    frames = [make_frame(rng, w, h, False) for (w, h) in shapes]
+    rb = RawBatch(shapes, frames, [2, 1])
+    db = DeviceLossyBatch(rb, "cuda:0")
+    # corrupt frame 1 on the device: MB 9 points at the frame's last block (its further blocks fall off the end), MB 12 far
+    # beyond it, MB 15 1.5 GB beyond it
+    nblk = frames[1][1].size // 16
+    mb1 = frames[1][0].reshape(-1, 4).copy()
+    counts = [bin(int(w) & 0x00ffffff).count("1") + ((int(w) >> 24) & 1) for w in mb1[:, 2]]
+    with_blocks = [m for m, c in enumerate(counts) if c >= 2]
+    assert len(with_blocks) >= 3
+    victims = dict(zip((with_blocks[1], with_blocks[len(with_blocks) // 2], with_blocks[-1]), (nblk - 1, nblk + 12345, 0x03000000)))
+    mbd = db.mb.view(torch.int32).view(-1, 4)
+    base = rb.desc[1].mb_base
+    for m, idx in victims.items():
+        mbd[base + m, 3] = idx
+    torch.cuda.synchronize()
+    # what the bounded fetches amount to: out-of-range blocks are zeros
+    co = frames[1][1].reshape(-1, 16)
+    exp_co = np.concatenate([co, np.zeros((26 * len(victims), 16), np.int16)])
+    exp_mb = mb1.copy()
+    nxt = nblk
+    for m, idx in victims.items():
+        cnt = bin(int(mb1[m, 2]) & 0x00ffffff).count("1") + ((int(mb1[m, 2]) >> 24) & 1)
+        exp_mb[m, 3] = nxt
+        if idx == nblk - 1:                      # its first block is the frame's last one, the rest is out of range
+            exp_co[nxt] = co[nblk - 1]
+        nxt += cnt
+    want = [oracle.vp8_from_packed(5, 4, frames[0][0], frames[0][1], frames[0][2], 2),
+            oracle.vp8_from_packed(7, 3, exp_mb.reshape(-1), exp_co.reshape(-1), frames[1][2], 1)]
+    for path in ("one_kernel", "recon_only"):
+        for t in (db.y, db.u, db.v):
+            t.zero_()
+        if path == "one_kernel":
+            db.decode_to_argb()
+            key = ("y", "u", "v")
+        else:
+            db.recon(planes=True)
+            key = ("y0", "u0", "v0")                # the unfiltered planes
+        torch.cuda.synchronize()
+        for i in range(2):
+            got = db.planes(i)
+            for name, g in zip(key, got):
+                assert np.array_equal(g, want[i][name]), "%s: plane %s of frame %d" % (path, name, i)
+
+
 @pytest.mark.parametrize("shape", [(1024, 5), (3, 1024), (1024, 1)])
 def test_maximum_dimensions(shape):
     """The largest macroblock grid a VP8 frame header can describe in one direction (14-bit dimensions: 16383 px = 1024

@@ -164,3 +164,31 @@ def test_files_decode_with_the_pixel_loop_on_the_device():
     for path, data, img in zip(FILES, datas, images):
         want = oracle.decode(data)
         assert want["kind"] == "argb" and np.array_equal(img.data.pix, want["argb"]), path
+
+
+def test_mixed_batch_of_tokenized_and_host_resolved_frames():
+    """decode_batch on files parsed both ways at once: LosslessBatch then holds token streams for some frames and pixels for
+    the others in one slab, and wp_vp8l_resolve must hand the others' bytes back untouched (it once returned uninitialised
+    device memory for them).  Both kinds must equal the oracle's decode."""
+    from oracle import oracle
+    from webp_amd.decoder import LosslessBatch, decode_batch, parse
+    paths = [os.path.join(ROOT, "tests", "golden", "inputs", n) for n in ("1ll.webp", "5ll.webp", "4ll.webp", "2ll.webp")]
+    datas = [open(p, "rb").read() for p in paths]
+    files = [parse(d, vp8l_tokens=(i % 2 == 0)) for i, d in enumerate(datas)]
+    lb = LosslessBatch([f.frames[0] for f in files])
+    assert lb.n_tok == 2 and lb.n == 4
+    # the slab level: after resolve(), host-resolved frames still hold their pixels and tokenized ones hold decodePix's output
+    before = lb.pix.copy()
+    lb.resolve()
+    for i, f in enumerate(files):
+        d = lb.desc[i]
+        sl = slice(int(d.pix_off), int(d.pix_off) + 4 * d.coded_width * d.height)
+        if i % 2:
+            assert np.array_equal(lb.pix[sl], before[sl]), "host-resolved frame %d was overwritten by wp_vp8l_resolve" % i
+        else:
+            want = parse(datas[i]).frames[0].buf(3)
+            assert np.array_equal(lb.pix[sl], want), "tokenized frame %d" % i
+    # the API level
+    for img, d in zip(decode_batch(files), datas):
+        want = oracle.decode(d)
+        assert np.array_equal(img.data.pix, want["argb"])

@@ -27,6 +27,7 @@ def _outputs(db):
 def test_static_workspace_entry_point_matches_the_workspace_one():
     import torch
     from packed_util import random_batch
+    from webp_amd._lib import check, lib
     from webp_amd.device import DeviceLossyBatch
     # first call: 700 frames (more than the 512 persistent workgroups), ~20 MB of tiles; second call: 40 frames
     for n, seed in ((700, 31), (40, 32)):
@@ -39,10 +40,19 @@ def test_static_workspace_entry_point_matches_the_workspace_one():
         want = _outputs(db)
         for t in (db.y, db.u, db.v, db.argb):
             t.zero_()
+        # "allocates nothing" at the level of the driver, not only of torch's caching allocator (which a hipMalloc inside the
+        # library would never show up in): free device memory as the driver reports it, before and after the call, with the
+        # library's one-time set-up (wp_init: side stream, the static array's address) done beforehand
+        check(lib().wp_init(0))
+        torch.cuda.synchronize()
+        free_before, _ = torch.cuda.mem_get_info()
         mem_before = torch.cuda.memory_allocated()
         _static_call(db)
-        got = _outputs(db)
+        torch.cuda.synchronize()
+        free_after, _ = torch.cuda.mem_get_info()
         assert torch.cuda.memory_allocated() == mem_before
+        assert free_after == free_before, "free device memory moved by %d bytes across the static call" % (free_before - free_after)
+        got = _outputs(db)
         for name, g, w in zip("yuva", got, want):
             assert np.array_equal(g, w), "n=%d: output %s of the static-workspace call differs" % (n, name)
         for i in (0, n // 2, n - 1):              # and both equal the oracle

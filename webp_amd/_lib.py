@@ -15,7 +15,11 @@ class Vp8Frame(ctypes.Structure):          # wp_vp8_frame
                 ("filter_type", ctypes.c_int32), ("has_alpha", ctypes.c_int32), ("mb_base", ctypes.c_uint32),
                 ("stile_base", ctypes.c_uint32), ("coeff_base", ctypes.c_uint64), ("y_off", ctypes.c_uint64),
                 ("u_off", ctypes.c_uint64), ("v_off", ctypes.c_uint64), ("argb_off", ctypes.c_uint64),
-                ("alpha_off", ctypes.c_uint64), ("cost", ctypes.c_uint32), ("turn", ctypes.c_uint32)]
+                ("alpha_off", ctypes.c_uint64), ("cost", ctypes.c_uint32), ("turn", ctypes.c_uint32),
+                ("coeff_blocks", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
+
+
+FRAME_COEFF_BOUNDED = 1                    # WP_FRAME_COEFF_BOUNDED
 
 
 class Vp8lTransform(ctypes.Structure):     # wp_vp8l_transform

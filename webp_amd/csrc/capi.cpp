@@ -48,6 +48,7 @@ namespace {
 thread_local std::string g_error;
 std::atomic<int> g_cus{0};      // compute units of the device (all devices of a node are the same part)
 std::atomic<int> g_launch_cap{0};   // wp_debug_set_frames_per_launch: test hook, 0 = off
+constexpr int kDefaultCus = 256;    // MI355X; used by the host-side layout functions until wp_init has read the real count
 
 int fail(int code, const std::string& msg) { g_error = msg; return code; }
 int hip_fail(hipError_t e, const char* what) { return fail(WP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
@@ -132,7 +133,8 @@ int frames_per_launch(int n, const wp_vp8_frame* f, int phases = 1) {      // ph
     long long max_bands = 1;
     for (int i = 0; i < n; ++i) max_bands = std::max(max_bands, (long long)(f[i].mbh + 3) / 4);
     const long long per_wg = std::max(1LL, (1LL << 19) / (max_bands * phases));
-    long long per = std::min<long long>(n, per_wg * std::max(1, g_cus.load(std::memory_order_relaxed)));
+    const int cus_now = g_cus.load(std::memory_order_relaxed);
+    long long per = std::min<long long>(n, per_wg * (cus_now > 0 ? cus_now : kDefaultCus));
     const int cap = g_launch_cap.load(std::memory_order_relaxed);
     if (cap > 0) per = std::min<long long>(per, cap);
     return int(std::max(1LL, per));
@@ -145,7 +147,11 @@ int frames_per_launch(int n, const wp_vp8_frame* f, int phases = 1) {      // ph
 // got the heaviest frame of a round gets the lightest of the next.
 void assign_turns(int n, wp_vp8_frame* f) {
     const int per = frames_per_launch(n, f);
-    const int grid = std::max(1, wpk_mb_wgs_per_cu() * g_cus.load(std::memory_order_relaxed));      // the kernel's persistent workgroups
+    // the kernel's persistent workgroups.  Before wp_init has seen the device (a parser / worker process that only lays out
+    // batches never touches the GPU) the part's own figure stands in: 256 CUs on MI355X.  A schedule laid out for another
+    // grid is still a permutation -- it only balances less well.
+    const int cus = g_cus.load(std::memory_order_relaxed);
+    const int grid = std::max(1, wpk_mb_wgs_per_cu() * (cus > 0 ? cus : kDefaultCus));
     std::vector<uint32_t> order;
     for (int first = 0; first < n; first += per) {
         const int cnt = std::min(per, n - first);
@@ -166,11 +172,23 @@ void assign_turns(int n, wp_vp8_frame* f) {
 bool turns_valid(int cnt, const wp_vp8_frame* f) {
     static const bool off = std::getenv("WP_NO_TURNS") != nullptr;      // tuning switch: slot order
     if (off) return false;
-    thread_local std::vector<uint8_t> seen;
-    seen.assign(size_t(cnt), 0);
+    // a bitmap on the stack for launches of up to 65536 frames (every batch the static entry point accepts is far smaller:
+    // it must not allocate, on the host either); the heap only beyond that
+    constexpr int kStackFrames = 1 << 16;
+    uint64_t stack_bits[kStackFrames / 64];
+    std::vector<uint64_t> heap_bits;
+    uint64_t* bits = stack_bits;
+    const size_t words = (size_t(cnt) + 63) / 64;
+    if (cnt > kStackFrames) {
+        try { heap_bits.assign(words, 0); } catch (const std::bad_alloc&) { return false; }
+        bits = heap_bits.data();
+    } else {
+        std::memset(stack_bits, 0, words * sizeof(uint64_t));
+    }
     for (int i = 0; i < cnt; ++i) {
-        if (f[i].turn >= uint32_t(cnt) || seen[f[i].turn]) return false;
-        seen[f[i].turn] = 1;
+        const uint32_t t = f[i].turn;
+        if (t >= uint32_t(cnt) || ((bits[t >> 6] >> (t & 63)) & 1)) return false;
+        bits[t >> 6] |= uint64_t(1) << (t & 63);
     }
     return true;
 }
@@ -271,8 +289,7 @@ int wp_vp8_plan(int n, wp_vp8_frame* frames, uint64_t* work_bytes) {
         st += size_t(frames[i].mbw + 1) * size_t(frames[i].mbh + 1);
     }
     if (work_bytes) *work_bytes = uint64_t(vp8_work(n, frames).total);
-    if (g_cus.load(std::memory_order_relaxed) <= 0) (void)wp_init(-1);      // the schedule depends on the GPU's CU count; without a GPU the default stands
-    assign_turns(n, frames);
+    assign_turns(n, frames);                // host arithmetic only: planning a batch does not touch the GPU
     return WP_OK;
 }
 
@@ -584,7 +601,11 @@ int check_vp8_records(int n, const wp_vp8_frame* frames, const uint32_t* mb, siz
         if (size_t(frames[i].mb_base) + size_t(frames[i].mbw) * frames[i].mbh > n_mb) return fail(WP_ERR_INVALID, "mb_base out of range");
         if (!mb) continue;
         if (frames[i].coeff_base > n_coeff_blocks) return fail(WP_ERR_INVALID, "coeff_base out of range");
-        const size_t avail = n_coeff_blocks - size_t(frames[i].coeff_base);
+        size_t avail = n_coeff_blocks - size_t(frames[i].coeff_base);
+        if (frames[i].flags & WP_FRAME_COEFF_BOUNDED) {
+            if (size_t(frames[i].coeff_blocks) > avail) return fail(WP_ERR_INVALID, "coeff_blocks of frame " + std::to_string(i) + " reaches beyond the coefficient array");
+            avail = size_t(frames[i].coeff_blocks);
+        }
         if (avail && !coeff) return fail(WP_ERR_INVALID, "null coefficient array");
         const uint32_t* rec = mb + size_t(frames[i].mb_base) * WP_MB_WORDS;
         for (size_t m = 0, e = size_t(frames[i].mbw) * frames[i].mbh; m < e; ++m, rec += WP_MB_WORDS) {
@@ -594,6 +615,15 @@ int check_vp8_records(int n, const wp_vp8_frame* frames, const uint32_t* mb, siz
         }
     }
     return WP_OK;
+}
+// The host-pointer entry points know the coefficient array's length: every frame that did not bring a bound of its own gets
+// the rest of the array as its bound, so the device never reads beyond the uploaded slab.
+void bound_frames(std::vector<wp_vp8_frame>& f, size_t n_coeff_blocks) {
+    for (wp_vp8_frame& a : f) {
+        if (a.flags & WP_FRAME_COEFF_BOUNDED) continue;
+        a.coeff_blocks = uint32_t(std::min<uint64_t>(0xffffffffull, uint64_t(n_coeff_blocks) - a.coeff_base));
+        a.flags |= WP_FRAME_COEFF_BOUNDED;
+    }
 }
 }  // namespace
 
@@ -614,6 +644,7 @@ int wp_vp8_decode_to_argb(int n, const wp_vp8_frame* frames, const uint32_t* mb,
     try { planned.assign(frames, frames + n); } catch (const std::bad_alloc&) { return fail(WP_ERR_NOMEM, "out of memory"); }
     uint64_t work_bytes = 0;
     if ((rc = wp_vp8_plan(n, planned.data(), &work_bytes))) return rc;
+    bound_frames(planned, n_coeff_blocks);
     frames = planned.data();
     const bool want_planes = out_y || out_u || out_v;
     DevBuf dfr, dmb, dfl, dco, dy, du, dv, da, dargb, dwork;
@@ -651,6 +682,7 @@ int wp_vp8_recon(int n, const wp_vp8_frame* frames, const uint32_t* mb, size_t n
     try { planned.assign(frames, frames + n); } catch (const std::bad_alloc&) { return fail(WP_ERR_NOMEM, "out of memory"); }
     uint64_t work_bytes = 0;
     if ((rc = wp_vp8_plan(n, planned.data(), &work_bytes))) return rc;
+    bound_frames(planned, n_coeff_blocks);
     DevBuf dfr, dmb, dco, dy, du, dv, dwork;
     if ((rc = dfr.upload(planned.data(), sizeof(wp_vp8_frame) * size_t(n))) || (rc = dwork.alloc(size_t(work_bytes))) ||
         (rc = dmb.upload(mb, n_mb * 16)) || (rc = dco.upload(coeff, n_coeff_blocks * 32)) ||
@@ -774,7 +806,8 @@ int wp_vp8l_resolve(int n, const wp_vp8l_tokens_frame* frames, const uint32_t* t
         if ((rc = wp_vp8l_check_tokens(&a, tokens + a.tok_off / 4))) return rc;
     }
     DevBuf dfr, dtok, dpix;
-    if ((rc = dfr.upload(frames, sizeof(wp_vp8l_tokens_frame) * size_t(n))) || (rc = dtok.upload(tokens, n_words * 4)) || (rc = dpix.alloc(pix_len))) return rc;
+    if ((rc = dfr.upload(frames, sizeof(wp_vp8l_tokens_frame) * size_t(n))) || (rc = dtok.upload(tokens, n_words * 4)) ||
+        (rc = dpix.upload(pix, pix_len))) return rc;      // the slab may hold other frames' pixels (host-resolved ones): they go up and come back unchanged
     rc = wp_vp8l_resolve_dev(n, frames, dfr.as<wp_vp8l_tokens_frame>(), dtok.as<uint32_t>(), dpix.as<uint8_t>(), nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -1005,6 +1038,8 @@ int wp_vp8_batch_layout(int n, const wp_parsed* const* files, const int* frame_i
         d.filter_type = f->vp8.filter_type;
         d.has_alpha = (with_alpha && with_alpha[i]) ? 1 : 0;
         d.mb_base = uint32_t(z.n_mb); d.stile_base = uint32_t(st); d.coeff_base = z.n_coeff_blocks;
+        if (f->vp8.coeff.size() / 16 > 0xffffffffull) return fail(WP_ERR_INVALID, "frame has more coefficient blocks than a 32-bit count holds");
+        d.coeff_blocks = uint32_t(f->vp8.coeff.size() / 16); d.flags = WP_FRAME_COEFF_BOUNDED;
         d.y_off = z.y_bytes; d.u_off = z.u_bytes; d.v_off = z.v_bytes; d.argb_off = z.argb_bytes; d.alpha_off = z.alpha_bytes;
         z.n_mb += nmb;
         st += uint64_t(d.mbw + 1) * uint64_t(d.mbh + 1);
@@ -1019,7 +1054,6 @@ int wp_vp8_batch_layout(int n, const wp_parsed* const* files, const int* frame_i
         if (d.has_alpha) z.alpha_bytes += align_up(size_t(d.width) * size_t(d.height), 256);
     }
     const int rc = check_vp8_frames(n, frames); if (rc) return rc;
-    if (g_cus.load(std::memory_order_relaxed) <= 0) (void)wp_init(-1);
     assign_turns(n, frames);
     z.work_bytes = uint64_t(vp8_work(n, frames).total);
     *sizes = z;

@@ -58,16 +58,6 @@ struct alignas(16) MbWaveLds {
     MbGroupLds grp[kBandRows];
 };
 
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-constexpr uint32_t kOob = 0xFFFFFF00u;                   // beyond every buffer resource below: the load returns zeros
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void* p) {      // raw buffer, 2 GB window from p
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x80000000u, 0x00020000);
-}
-__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t off, bool nt) {
-    const v4i_t v = nt ? __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 2) : __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
-    return make_uint4(uint32_t(v.x), uint32_t(v.y), uint32_t(v.z), uint32_t(v.w));
-}
-
 // The lane's roles are re-derived from an opaque copy of the lane id at the start of the two halves of a step: derived
 // values (group, block, row / column roles, LDS addresses, lane masks) would otherwise be hoisted out of the step loop
 // and each hold a register -- vector or, for the masks, a scalar pair -- for the whole band (the first version kept ~40
@@ -90,9 +80,11 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
     const int n_steps = mbw + 2 * (rows_here - 1);
     // Inputs: wave-uniform buffer resources (scalar registers) + 32-bit per-lane byte offsets; a frame's records and
     // coefficient blocks (<= 25 x 32 B per MB) stay below 2 GB for the largest frame (1024 x 1024 MBs).
-    const __amdgpu_buffer_rsrc_t mb_rs = buffer_of(mb + size_t(fr.mb_base));
-    const __amdgpu_buffer_rsrc_t fl_rs = buffer_of(filt + size_t(fr.mb_base));
-    const __amdgpu_buffer_rsrc_t co_rs = buffer_of(coeff + size_t(fr.coeff_base) * 16);
+    // The record arrays are as long as the frame has macroblocks; the coefficient window is the frame's own blocks when the
+    // descriptor says how many there are (WP_FRAME_COEFF_BOUNDED): a malformed block index then reads zeros, not foreign memory.
+    const __amdgpu_buffer_rsrc_t mb_rs = buffer_of(mb + size_t(fr.mb_base), uint32_t(mbw) * uint32_t(mbh) * 16u);
+    const __amdgpu_buffer_rsrc_t fl_rs = buffer_of(filt + size_t(fr.mb_base), uint32_t(mbw) * uint32_t(mbh) * 4u);
+    const __amdgpu_buffer_rsrc_t co_rs = buffer_of(coeff + size_t(fr.coeff_base) * 16, coeff_window_bytes(fr));
     const uint32_t erow = uint32_t(band) * uint32_t(mbw) * uint32_t(kEdgeBytes);                       // edge rows this band leaves behind
     const uint32_t etop = uint32_t(has_above ? band - 1 : 0) * uint32_t(mbw) * uint32_t(kEdgeBytes);   // ... and those of the band above
 

@@ -16,6 +16,24 @@ struct ReconWaveLds {
     uint32_t ring[kBandRows][4][8];   // ring[g][col & 3]: bottom row of the MB above group g: Y (4 dwords), U (2), V (2)
 };
 
+// Inputs are read through buffer resources (wave-uniform base in scalar registers + a 32-bit byte offset per lane): a lane
+// with nothing to fetch uses an out-of-range offset and gets zeros back, without a branch and without memory traffic, and
+// the hardware range check keeps a malformed block index inside the window.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+constexpr uint32_t kOob = 0xFFFFFF00u;                   // beyond every buffer resource below: the load returns zeros
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void* p, uint32_t bytes) {      // raw buffer of `bytes` bytes from p
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, int(bytes), 0x00020000);
+}
+// the frame's own coefficient blocks when the descriptor bounds them, else a 2 GB window (offsets are 32-bit; the largest
+// frame, 1024 x 1024 macroblocks x 25 blocks, stays below it)
+__device__ __forceinline__ uint32_t coeff_window_bytes(const wp_vp8_frame& fr) {
+    return (fr.flags & WP_FRAME_COEFF_BOUNDED) ? min(fr.coeff_blocks, 0x03ffffffu) * 32u : 0x80000000u;
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t off, bool nt) {
+    const v4i_t v = nt ? __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 2) : __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_uint4(uint32_t(v.x), uint32_t(v.y), uint32_t(v.z), uint32_t(v.w));
+}
+
 __device__ __forceinline__ uint32_t& tile32(uint8_t* row, int col) { return *reinterpret_cast<uint32_t*>(row + col); }
 
 __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) { return uint32_t(a) | uint32_t(b) << 8 | uint32_t(c) << 16 | uint32_t(d) << 24; }
@@ -249,9 +267,9 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
     // it the lane's luma coefficient block and WHT coefficient one step ahead (registers).  prefetch(s) is what
     // step s issues: the record of MB x+2 and, from the record of MB x+1 (fetched by the previous call), the
     // coefficients of MB x+1.
-    const uint4* mb_row = mb + size_t(fr.mb_base) + size_t(row_ok ? y : 0) * mbw;
     uint8_t* const Rrow = R + size_t(row_ok ? y : 0) * mbw * kTileBytes;      // R tiles of this lane's MB row
-    const int16_t* const cfr = coeff + size_t(fr.coeff_base) * 16;
+    const __amdgpu_buffer_rsrc_t mb_rs = buffer_of(mb + size_t(fr.mb_base), uint32_t(mbw) * uint32_t(mbh) * 16u);
+    const __amdgpu_buffer_rsrc_t co_rs = buffer_of(coeff + size_t(fr.coeff_base) * 16, coeff_window_bytes(fr));
     uint4 rec_n1 = make_uint4(0, 0, 0, 0), rec_n2 = make_uint4(0, 0, 0, 0);     // records of MB x+1, x+2
     uint4 nl0 = make_uint4(0, 0, 0, 0), nl1 = make_uint4(0, 0, 0, 0);           // luma block l of MB x+1
     uint32_t nwv = 0;                                                           // WHT coefficient l of MB x+1
@@ -259,23 +277,22 @@ __device__ __forceinline__ void recon_band(const wp_vp8_frame& fr, int band, int
     const int cn = 16 + (l & 3) + ((l & 8) ? 4 : 0);                            // lanes 0-3: Cb blocks, 8-11: Cr blocks
     const bool chroma_lane = (l & 4) == 0;
     // Every lane issues every load of the prefetch, every step: a lane that has nothing to fetch (outside the frame, no
-    // stored block, no WHT) reads a block of zeros instead.  No branches, nothing to clear beforehand, and -- the count of
-    // loads per step being fixed -- the compiler can wait for the top-row loads issued before them without also
-    // waiting for these.
-    const uint4* const zero = wp_zero_block;
+    // stored block, no WHT) reads at an out-of-range offset and gets zeros.  No branches, nothing to clear beforehand, and
+    // -- the count of loads per step being fixed -- the compiler can wait for the top-row loads issued before them without
+    // also waiting for these.
     auto prefetch = [&](int s_) {
         const int x_ = s_ - 2 * g;
         rec_n1 = rec_n2;                                            // all zero for a lane whose MB x+1 is outside the frame
         const bool in2 = row_ok && x_ + 2 >= 0 && x_ + 2 < mbw;
-        rec_n2 = *(in2 ? mb_row + (x_ + 2) : zero);
+        rec_n2 = buf_load16(mb_rs, in2 ? (uint32_t(y) * uint32_t(mbw) + uint32_t(x_ + 2)) * 16u : kOob, false);
         const uint32_t w2n = rec_n1.z;
-        const int whtn = (w2n >> WP_MB_WHT_BIT) & 1;
-        const int16_t* cbn = cfr + size_t(rec_n1.w) * 16;      // a block index can need more than 32 bits once scaled: 64-bit
-        const uint4* lp = ((w2n >> l) & 1) ? reinterpret_cast<const uint4*>(cbn + uint32_t(whtn + __popc(w2n & ((1u << l) - 1u))) * 16u) : zero;
-        nl0 = ld_nt(lp); nl1 = ld_nt(lp + 1);
-        nwv = uint32_t(int(*(whtn ? cbn + l : reinterpret_cast<const int16_t*>(zero))));
-        const uint4* cp = (chroma_lane && ((w2n >> cn) & 1)) ? reinterpret_cast<const uint4*>(cbn + uint32_t(whtn + __popc(w2n & ((1u << cn) - 1u))) * 16u) : zero;
-        nc0 = ld_nt(cp); nc1 = ld_nt(cp + 1);
+        const uint32_t whtn = (w2n >> WP_MB_WHT_BIT) & 1u;
+        const uint32_t blk0 = rec_n1.w + whtn;                                  // first non-WHT block of MB x+1
+        const uint32_t lo = ((w2n >> l) & 1) ? (blk0 + uint32_t(__popc(w2n & ((1u << l) - 1u)))) * 32u : kOob;
+        nl0 = buf_load16(co_rs, lo, true); nl1 = buf_load16(co_rs, lo + 16u, true);
+        nwv = uint32_t(int(int16_t(__builtin_amdgcn_raw_buffer_load_b16(co_rs, whtn ? rec_n1.w * 32u + 2u * uint32_t(l) : kOob, 0, 0))));
+        const uint32_t cofs = (chroma_lane && ((w2n >> cn) & 1)) ? (blk0 + uint32_t(__popc(w2n & ((1u << cn) - 1u)))) * 32u : kOob;
+        nc0 = buf_load16(co_rs, cofs, true); nc1 = buf_load16(co_rs, cofs + 16u, true);
     };
     prefetch(-2);
     prefetch(-1);

@@ -21,6 +21,9 @@ constexpr uint32_t kRingPx = 16384, kRingMask = kRingPx - 1;
 constexpr uint32_t kCopyPiece = 4096;                       // the longest copy the bitstream can code (Vp8LDecoder.hx:337-345); longer ones are taken in pieces
 constexpr uint32_t kRingReach = kRingPx - kCopyPiece - 64;  // copies up to this distance never see a ring slot reused under them
 constexpr int kMaxCacheBits = 11;                           // Vp8LDecoder.hx:228
+// LDS budget: 64 KiB ring + two 8 KiB cache arrays = 80 KiB per wavefront.  That is a gfx950 budget (160 KiB per CU: two
+// images resident per CU); the library is built for gfx950 only (Makefile ARCH), and a 64 KiB-LDS part could not hold it.
+static_assert((kRingPx + 2u * (1u << kMaxCacheBits)) * 4u <= 160u * 1024u / 2u, "vp8l_resolve_kernel: two wavefronts' LDS must fit gfx950's 160 KiB per CU");
 
 __device__ __forceinline__ uint32_t lane_word(uint32_t v, uint32_t l) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(l))); }
 __device__ __forceinline__ uint32_t far_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

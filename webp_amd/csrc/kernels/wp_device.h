@@ -62,8 +62,6 @@ __device__ __forceinline__ void st_nt(uint4* p, uint4 v) { const u32x4_t w = {v.
 __device__ __forceinline__ void st_nt(uint2* p, uint2 v) { const u32x2_t w = {v.x, v.y}; __builtin_nontemporal_store(w, reinterpret_cast<u32x2_t*>(p)); }
 #endif
 
-// 32 bytes of zeros in device memory: what a lane loads when it has nothing to load (vp8_recon_band.h).
-static __device__ const uint4 wp_zero_block[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 
 // Packed 16-bit helpers shared by the lossy and the lossless kernels.
 typedef short short2_t __attribute__((ext_vector_type(2)));

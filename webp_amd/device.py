@@ -216,7 +216,7 @@ class LossyPipeline:
                     done_prev = self._event(self.s_finish)
                 self._phase2_done = done_prev
                 self._finish_hist.append(done_prev)
-                del self._finish_hist[:-4]
+                del self._finish_hist[:-max(4, self.workspaces)]      # the wait above looks workspaces - 1 entries back
                 self._queued.append(done_prev)
                 if ptiming is not None:
                     ptiming.append(pmarks)
