@@ -46,7 +46,7 @@ __device__ __forceinline__ int clamp255(int v) { return clampi(v, 0, 255); }
 
 // filter2, one position (Filter.hx:29-50)
 __device__ __forceinline__ void simple_edge(int p1, int& p0, int& q0, int q1, int level, bool use) {
-    const bool on = use && (absdiff(p0, q0) << 1) + (absdiff(p1, q1) >> 1) <= level;
+    const bool on = use & ((absdiff(p0, q0) << 1) + (absdiff(p1, q1) >> 1) <= level);
     const int a = on ? __mul24(q0 - p0, 3) + clamp127(p1 - q1) : 0;
     const int a1 = clamp15((a + 4) >> 3);
     const int a2 = clamp15((a + 3) >> 3);
@@ -60,7 +60,7 @@ __device__ __forceinline__ void normal_edge(int p3, int& p2, int& p1, int& p0, i
                                             int level, int ilevel, int hlevel, bool use) {
     const int m10 = max(absdiff(p1, p0), absdiff(q0, q1));
     const int worst = max(max(max(absdiff(p3, p2), absdiff(p2, p1)), m10), max(absdiff(q1, q2), absdiff(q2, q3)));
-    const bool on = use && (absdiff(p0, q0) << 1) + (absdiff(p1, q1) >> 1) <= level && worst <= ilevel;
+    const bool on = use & ((absdiff(p0, q0) << 1) + (absdiff(p1, q1) >> 1) <= level) & (worst <= ilevel);      // & not &&: no branch around the mask terms
     const bool hev = m10 > hlevel;
     const int base = __mul24(q0 - p0, 3);
     const int outer = clamp127(p1 - q1);

@@ -25,6 +25,10 @@ __global__ __launch_bounds__(256)
 void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* __restrict__ Rp, const uint8_t* __restrict__ Sp,
                        int force_unshifted, uint8_t* Yp, uint8_t* Up, uint8_t* Vp, const uint8_t* __restrict__ Ap, uint8_t* out) {
     __shared__ uint4 tiles4[kFinishLdsBytes / 16];
+#ifdef WP_FINISH_PAD_LDS      // tuning experiment: cap the pass's residency (workgroups per CU) as if another kernel held the rest of the LDS
+    __shared__ uint32_t pad_lds[WP_FINISH_PAD_LDS / 4];
+    if (Yp == nullptr && out == nullptr && Up == nullptr) pad_lds[threadIdx.x] = 1;
+#endif
     const wp_vp8_frame& fr = frames[blockIdx.z];
     const bool shifted = !force_unshifted;
     const int t = int(threadIdx.x);

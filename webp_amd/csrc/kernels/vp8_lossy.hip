@@ -19,7 +19,14 @@ namespace wpk {
 constexpr int kMbWaves = WP_MB_WAVES;
 constexpr int kMbWGsPerCU = WP_MB_WGS_PER_CU;
 
-__global__ __launch_bounds__(kMbWaves * kWave, (kMbWaves * kMbWGsPerCU + 3) / 4)
+// Register budget: 112 VGPRs.  Two workgroups of this kernel leave a SIMD 512 - 4 x 112 = 64 registers per lane: two waves of
+// the finishing pass (32 each), which is what a pipelined step runs beside it.  At 113..128 only ONE fits and the step gets
+// 8 % longer although this kernel alone gets faster -- and the register allocator, which only sees that LDS caps the kernel
+// at 4 waves per SIMD anyway, uses up to 128 freely.  (The attribute counts in units of two registers on gfx90a and later.)
+#ifndef WP_MB_NUM_VGPR
+#define WP_MB_NUM_VGPR 56
+#endif
+__global__ __attribute__((amdgpu_num_vgpr(WP_MB_NUM_VGPR))) __launch_bounds__(kMbWaves * kWave, (kMbWaves * kMbWGsPerCU + 3) / 4)
 void vp8_mb_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, int use_turns, const uint4* __restrict__ mb,
                    const int16_t* __restrict__ coeff, const uint32_t* __restrict__ filt, uint8_t* Ep, uint8_t* Sp) {
     __shared__ MbWaveLds lds_all[kMbWaves];

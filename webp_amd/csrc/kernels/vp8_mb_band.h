@@ -8,7 +8,7 @@
 // the loop filter vp8_filter_band.h's (simpleFilter / normalFilter, Vp8Decoder.hx:417-486; Filter.hx); intra prediction
 // keeps reading UNFILTERED neighbours (Vp8Decoder.hx:561-569) because the two halves keep separate LDS state:
 //   ReconTile      the reference's ybr workspace (unfiltered MB + its borders), plus a 4-slot ring with the unfiltered
-//                  bottom row of the MB row above;
+//                  bottom row of the MB row above (kept in the pad columns of MbFilterTile's luma rows);
 //   MbFilterTile   4 rows above + the group's own 16 luma rows (chroma: 4 + 8) in two MB slots, slot = x & 1: the
 //                  previous MB's slot is the left neighbour.  Columns are absolute columns mod 32 (chroma: mod 16), so
 //                  the group above hands its 4 bottom rows down by writing them straight into rows 0..3 of this tile;
@@ -50,10 +50,13 @@ struct alignas(16) MbFilterTile {
 };
 struct alignas(16) MbGroupLds {                          // everything one group (one MB row of the band) keeps in LDS: one base address per lane
     ReconTile rt;
-    uint32_t rring[4][8];                                // rring[col & 3]: unfiltered bottom row of the MB above: Y (4 dwords), U (2), V (2)
     MbFilterTile ft;
-};                                                       // 960 + 128 + 1344 = 2432 B = 608 dwords: 9728 B per wavefront, 77.9 KB per workgroup:
-                                                         // two workgroups leave a CU 8 KB of LDS, enough for a finishing-pass workgroup beside them
+    // The ring with the unfiltered bottom row of the MB row above (slot = column & 3; Y 4 dwords, U 2, V 2) lives in the
+    // 16 pad bytes of the filter tile's luma rows (columns 32..47, which only exist for the bank layout): slot k = rows 2k
+    // and 2k + 1.  That is 128 bytes per group the workgroup does not have to own: 73.7 KB instead of 77.8, so that two
+    // workgroups leave a CU 16 KB of LDS for the finishing pass beside them.
+    __device__ __forceinline__ uint32_t& rring(int slot, int i) { return *reinterpret_cast<uint32_t*>(&ft.y[2 * slot + (i >> 2)][32 + 4 * (i & 3)]); }
+};                                                       // 960 + 1344 = 2304 B = 576 dwords: 9216 B per wavefront, 73.7 KB per workgroup
 struct alignas(16) MbWaveLds {
     MbGroupLds grp[kBandRows];
 };
@@ -113,7 +116,11 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
         nl0 = buf_load16(co_rs, lo, true); nl1 = buf_load16(co_rs, lo + 16u, true);
         nwv = uint32_t(int(int16_t(__builtin_amdgcn_raw_buffer_load_b16(co_rs, whtn ? rec_n1.w * 32u + 2u * uint32_t(l) : kOob, 0, 0))));   // the builtin's result is unsigned
         const uint32_t cofs = ((l & 4) == 0 && ((w2n >> cn) & 1)) ? (blk0 + uint32_t(__popc(w2n & ((1u << cn) - 1u)))) * 32u : kOob;
+#ifdef WP_KO_CHROMA_AC      // timing-only build: chroma DC only (what a register budget without the chroma AC prefetch would buy)
+        nc0.x = uint32_t(__builtin_amdgcn_raw_buffer_load_b16(co_rs, cofs, 0, 0));
+#else
         nc0 = buf_load16(co_rs, cofs, true); nc1 = buf_load16(co_rs, cofs + 16u, true);
+#endif
     };
     // Band boundary (group 0 only), per column: the unfiltered bottom row of the band above (lanes 0-7: one dword each of
     // its edge record) and the 4 filtered rows above (luma: lane = (row, 4-column quarter), chroma: lane = (plane, row,
@@ -133,7 +140,7 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
         if (has_above) {
             wait_progress(&progress[prev_wave], (q_prev << kSeqShift) | uint32_t(min(2, mbw)));
             if (ln < 16) {                                  // group 0
-                if (ln < 8) lds.grp[0].rring[0][ln] = *reinterpret_cast<const uint32_t*>(E + size_t(etop + 4u * uint32_t(ln)));
+                if (ln < 8) lds.grp[0].rring(0, ln) = *reinterpret_cast<const uint32_t*>(E + size_t(etop + 4u * uint32_t(ln)));
                 fetch_above(0, ln, mbw > 1);
             }
         }
@@ -162,7 +169,7 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
             fp = ftype != 0 ? nfp : 0u;
             // ---- band boundary: park the column fetched during the previous step, fetch the next ----
             if (has_above && s + 1 < mbw) {
-                if (ln < 8) lds.grp[0].rring[(s + 1) & 3][ln] = top_n;
+                if (ln < 8) lds.grp[0].rring((s + 1) & 3, ln) = top_n;
                 wait_progress(&progress[prev_wave], (q_prev << kSeqShift) | uint32_t(min(s + 3, mbw)));
                 if (ln < 16) fetch_above(s + 1, ln, s + 2 < mbw);
             }
@@ -185,7 +192,11 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
                 if (__builtin_amdgcn_ballot_w64(present || dc16 != 0) != 0) idct_residual(c, ev, od);
             }
             {
+#ifdef WP_KO_CHROMA_AC
+                const bool c_ac = false;
+#else
                 const bool c_ac = ((nc0.x >> 16) | nc0.y | nc0.z | nc0.w | nc1.x | nc1.y | nc1.z | nc1.w) != 0;
+#endif
                 if (__builtin_amdgcn_ballot_w64(c_ac) != 0) {
                     int c[16];
                     unpack_block(nc0, nc1, c);
@@ -210,9 +221,8 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
                     const int lc = min(l, 8);
                     uint32_t va = T.y[l][19], vb = T.y[16][19], vc1 = T.c[lc][11], vc2 = T.c[lc][27];     // last column of the previous MB
                     const bool tr_job = l == 4 || (l >= 10 && l <= 12);
-                    const uint32_t* slot = G.rring[x & 3];
-                    uint32_t rv = slot[l < 4 ? l : (l >= 6 && l <= 9) ? l - 2 : 3];
-                    const uint32_t nxt = G.rring[(x + 1) & 3][0];
+                    uint32_t rv = G.rring(x & 3, l < 4 ? l : (l >= 6 && l <= 9) ? l - 2 : 3);
+                    const uint32_t nxt = G.rring((x + 1) & 3, 0);
                     if (tr_job) rv = x == mbw - 1 ? splat4(int(rv >> 24)) : nxt;
                     if (x == 0) { va = 0x81; vb = 0x81; vc1 = 0x81; vc2 = 0x81; }
                     if (y == 0) {
@@ -246,7 +256,11 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
                 }
             }
             // ---- luma, 4x4: block (bj, bi) is ready at mini-step bi + 2*bj ----
+#ifdef WP_KO_I4             // timing-only build: no 4x4 luma prediction (what the ten mini-steps cost)
+            if (false) {
+#else
             if (__builtin_amdgcn_ballot_w64(act && !i16) != 0) {
+#endif
                 __builtin_amdgcn_s_setprio(WP_MB_PRIO_I4);
                 const int my_t = bi + 2 * bj;
                 const int mode4 = int(((l < 8 ? rec.x : rec.y) >> (4 * (l & 7))) & 15);
@@ -317,48 +331,50 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
                 //      loop filter has run) or, from the band's last row, to the edge buffer ----
                 if (l < 8) {
                     const uint32_t v = l < 4 ? tile32(T.y[16], 4 + 4 * l) : l < 6 ? tile32(T.c[8], 4 + 4 * (l - 4)) : tile32(T.c[8], 20 + 4 * (l - 6));
-                    if (g + 1 < kBandRows) GN.rring[x & 3][l] = v;
+                    if (g + 1 < kBandRows) GN.rring(x & 3, l) = v;
                     if (last_row && has_below) *reinterpret_cast<uint32_t*>(E + size_t(erow + uint32_t(x) * uint32_t(kEdgeBytes) + 4u * uint32_t(l))) = v;
                 }
-                // ---- copy into the loop filter's tile (lane = pixel row), and the 4 rows above at a band boundary ----
-                {
-                    uint8_t* yr = T.y[1 + l];
-                    t128(&F.y[4 + l][cb]) = make_uint4(tile32(yr, 4), tile32(yr, 8), tile32(yr, 12), tile32(yr, 16));
-                    uint8_t* cr = T.c[1 + lr];
-                    const int cc = lp ? 20 : 4;
-                    t64(&F.c[lp][4 + lr][cb8]) = make_uint2(tile32(cr, cc), tile32(cr, cc + 4));
-                }
+                // ---- the 4 rows above at a band boundary ----
                 if (g == 0 && y > 0) {
                     t32(&F.y[qr][cb + 4 * qd]) = cur_ty;
                     t32(&F.c[lp][hcr][cb8 + 4 * hh]) = cur_tc;
                 }
             }
-            __builtin_amdgcn_wave_barrier();
             WP_PROF_MARK(3);
-
-            if (ftype != 0) {
-                if (do_filter) {
-                    // ---- vertical edges: lane = pixel row; columns -4..15 relative to the MB ----
+            // ---- the MB moves from the reconstruction tile into the loop filter's tile (lane = pixel row) THROUGH the vertical
+            //      edges: each lane takes its luma row and its chroma row from T, filters them in registers (columns -4..-1 come
+            //      from the previous MB's slot of F) and stores them into F -- one LDS round trip instead of copy + reload ----
+            if (act) {
+                uint8_t* yr = T.y[1 + l];
+                uint4 w = make_uint4(tile32(yr, 4), tile32(yr, 8), tile32(yr, 12), tile32(yr, 16));
+                uint8_t* cr = T.c[1 + lr];
+                const int cc = lp ? 20 : 4;
+                uint2 wc = make_uint2(tile32(cr, cc), tile32(cr, cc + 4));
+                if (ftype != 0 && do_filter) {
                     {
                         int v[20];
                         unpack4(t32(&F.y[4 + l][pb + 12]), v);
-                        const uint4 w = t128(&F.y[4 + l][cb]);
                         unpack4(w.x, v + 4); unpack4(w.y, v + 8); unpack4(w.z, v + 12); unpack4(w.w, v + 16);
                         if (ftype == 1) filter_line<20, true>(v, x > 0, inner, level, ilevel, hlevel);
                         else filter_line<20, false>(v, x > 0, inner, level, ilevel, hlevel);
                         t32(&F.y[4 + l][pb + 12]) = pack4i(v);
-                        t128(&F.y[4 + l][cb]) = make_uint4(pack4i(v + 4), pack4i(v + 8), pack4i(v + 12), pack4i(v + 16));
+                        w = make_uint4(pack4i(v + 4), pack4i(v + 8), pack4i(v + 12), pack4i(v + 16));
                     }
                     if (ftype == 2) {
                         int v[12];
                         unpack4(t32(&F.c[lp][4 + lr][pb8 + 4]), v);
-                        const uint2 w = t64(&F.c[lp][4 + lr][cb8]);
-                        unpack4(w.x, v + 4); unpack4(w.y, v + 8);
+                        unpack4(wc.x, v + 4); unpack4(wc.y, v + 8);
                         filter_line<12, false>(v, x > 0, inner, level, ilevel, hlevel);
                         t32(&F.c[lp][4 + lr][pb8 + 4]) = pack4i(v);
-                        t64(&F.c[lp][4 + lr][cb8]) = make_uint2(pack4i(v + 4), pack4i(v + 8));
+                        wc = make_uint2(pack4i(v + 4), pack4i(v + 8));
                     }
                 }
+                t128(&F.y[4 + l][cb]) = w;
+                t64(&F.c[lp][4 + lr][cb8]) = wc;
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            if (ftype != 0) {
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_setprio(WP_MB_PRIO_H);
                 if (do_filter) {

@@ -47,9 +47,9 @@ __device__ __forceinline__ int mul16(int a, int c) { return __mul24(a, c) >> 16;
 
 
 // Residual of one 4x4 block: inverseDCT4 without the "+ prediction, clip8" tail
-// (Vp8Decoder.hx:905-935).  Row j comes back as two packed int16 pairs:
-// even[j] = (r[j][0], r[j][2]), odd[j] = (r[j][1], r[j][3]), each saturated to int16 (clip8(pred + r), computed with a
-// saturating add, cannot tell larger magnitudes apart, pred being in 0..255).
+// (Vp8Decoder.hx:905-935).  Row j comes back as two packed int16 pairs in pixel order:
+// even[j] = (r[j][0], r[j][1]), odd[j] = (r[j][2], r[j][3]) (the names are historical), each saturated to int16
+// (clip8(pred + r), computed with a saturating add, cannot tell larger magnitudes apart, pred being in 0..255).
 __device__ __forceinline__ void idct_residual(const int (&c)[16], uint32_t (&even)[4], uint32_t (&odd)[4]) {
     const int c1 = 85627, c2 = 35468;
     int m[4][4];
@@ -69,8 +69,8 @@ __device__ __forceinline__ void idct_residual(const int (&c)[16], uint32_t (&eve
         const int cc = mul16(m[1][j], c2) - mul16(m[3][j], c1);
         const int d = mul16(m[1][j], c1) + mul16(m[3][j], c2);
         // v_cvt_pk_i16_i32 saturates to int16 and packs in one instruction
-        even[j] = as_u32(__builtin_amdgcn_cvt_pk_i16((a + d) >> 3, (b - cc) >> 3));
-        odd[j] = as_u32(__builtin_amdgcn_cvt_pk_i16((b + cc) >> 3, (a - d) >> 3));
+        even[j] = as_u32(__builtin_amdgcn_cvt_pk_i16((a + d) >> 3, (b + cc) >> 3));
+        odd[j] = as_u32(__builtin_amdgcn_cvt_pk_i16((b - cc) >> 3, (a - d) >> 3));
     }
 }
 
@@ -112,19 +112,19 @@ __device__ __forceinline__ uint32_t avg3p(uint32_t a, uint32_t b, uint32_t c) {
 
 // clip8(pred + residual) for one row of four pixels (Vp8Decoder.hx:930-933, 991-996).
 __device__ __forceinline__ uint32_t add_clip_row(uint32_t pred, uint32_t even, uint32_t odd) {
-    return clip_pack(__builtin_elementwise_add_sat(as_s2(pred & 0x00ff00ffu), as_s2(even)),          // pixels 0, 2
-                     __builtin_elementwise_add_sat(as_s2((pred >> 8) & 0x00ff00ffu), as_s2(odd)));   // pixels 1, 3
+    return clip_pack_seq(__builtin_elementwise_add_sat(as_s2(WP_PERM(0u, pred, 0x0c010c00u)), as_s2(even)),     // pixels 0, 1 as int16
+                         __builtin_elementwise_add_sat(as_s2(WP_PERM(0u, pred, 0x0c030c02u)), as_s2(odd)));     // pixels 2, 3
 }
 
 // TrueMotion (PredFunc.hx TM variants): row r = clip(top + left[r] - corner), in packed 16-bit arithmetic
 __device__ __forceinline__ void pred_tm(uint32_t top4, uint32_t left4, int corner, uint32_t (&row)[4]) {
     const short2_t c2 = as_s2(uint32_t(corner) * 0x00010001u);
-    const short2_t t02 = as_s2(top4 & 0x00ff00ffu) - c2, t13 = as_s2((top4 >> 8) & 0x00ff00ffu) - c2;
+    const short2_t t01 = as_s2(WP_PERM(0u, top4, 0x0c010c00u)) - c2, t23 = as_s2(WP_PERM(0u, top4, 0x0c030c02u)) - c2;
     const uint32_t sel[4] = {0x0c000c00u, 0x0c010c01u, 0x0c020c02u, 0x0c030c03u};      // (left[r], 0, left[r], 0)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const short2_t lr = as_s2(WP_PERM(0u, left4, sel[r]));
-        row[r] = clip_pack(t02 + lr, t13 + lr);
+        row[r] = clip_pack_seq(t01 + lr, t23 + lr);
     }
 }
 

@@ -75,6 +75,15 @@ __device__ __forceinline__ uint32_t clip_pack(short2_t p02, short2_t p13) {
     return __builtin_amdgcn_perm(h8, l8, 0x05010400u);  // bytes: l8[0], h8[0], l8[1], h8[1]
 }
 
+// The same for pairs in pixel order -- (pixels 0, 1) and (pixels 2, 3): the second saturating pack writes the upper half of
+// the result directly (SDWA destination select), so no byte shuffle is needed afterwards.
+__device__ __forceinline__ uint32_t clip_pack_seq(short2_t p01, short2_t p23) {
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(as_u32(p01)));
+    asm("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(r) : "v"(as_u32(p23)));
+    return r;
+}
+
 // Optional per-phase cycle profile of the wavefront kernels (tuning builds only: -DWP_PROFILE).  Wave 0 of workgroup 0
 // accumulates s_memtime deltas per phase and adds them to wp_prof[] at the end of each band; tools read the symbol.
 #ifdef WP_PROFILE
