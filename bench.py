@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: batched 1080p lossy WebP, recon + loop filter + YUV->ARGB on MI355X.
 
-One "step" = one pass of the device pipeline (reconstruction, loop filter, finishing pass: three kernels, producing
-both the filtered YUV420 planes and ARGB) over a batch of synthetic encoded 1920x1080 VP8 images whose packed macroblock
-/ coefficient / filter buffers are already resident in HBM (the host entropy decode and the H2D copy happen once, before
-the timed region).  Successive steps are software-pipelined over two HIP streams (webp_amd.device.LossyPipeline): the
-memory-bound finishing pass of step k runs, in two halves, beside the issue-bound reconstruction and loop filter of step
-k+1; every step does all of its work and the timed region ends with both streams drained.  `--serial` runs the steps on one stream
+One "step" = one pass of the device pipeline (reconstruction + loop filter as one kernel, then the finishing pass,
+producing both the filtered YUV420 planes and ARGB) over a batch of synthetic encoded 1920x1080 VP8 images whose packed
+macroblock / coefficient / filter buffers are already resident in HBM (the host entropy decode and the H2D copy happen
+once, before the timed region).  Successive steps are software-pipelined by the library itself (wp_vp8_pipeline_* of the C
+ABI, csrc/pipeline.cpp: two HIP streams, rotating workspaces): the memory-bound finishing pass of step k runs beside the
+issue-bound kernel of step k+1; every step does all of its work and the timed region ends with both streams drained.  `--serial` runs the steps on one stream
 instead (each kernel alone on the GPU); `--alone` adds the single-stream figure to the pipelined run's JSON line.
 Metric: decoded Mpix/s, counting visible pixels, whole job over all GPUs.
 
@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--split", type=float, default=0.6, help="share of a step's frames whose finishing pass runs beside the next reconstruction (the rest: beside the next loop filter)")
     ap.add_argument("--finish-delay-us", type=float, default=40.0, help="how long a finishing pass is held back so that the persistent kernel of its phase is dispatched first")
     ap.add_argument("--two-phase", action="store_true", help="round-1 schedule: reconstruction and loop filter as two kernels (R tiles through HBM), the finishing pass of the step before split over both")
+    ap.add_argument("--py-pipeline", action="store_true", help="pipeline the steps with webp_amd.device.LossyPipeline (torch streams, torch.cuda._sleep as hold-off) instead of the library's own wp_vp8_pipeline_* (the default)")
     ap.add_argument("--workspaces", type=int, default=2, help="tile workspaces the pipelined steps rotate through")
     ap.add_argument("--alone", action="store_true", help="after the timed region also time the single-stream fused call (config.serial_ms_per_step)")
     args = ap.parse_args()
@@ -204,12 +205,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from webp_amd.device import LossyPipeline
+    from webp_amd.device import LossyPipeline, NativePipeline
     if args.serial:
         from webp_amd._lib import lib as _wl
         _wl().wp_hint_finish_overlap(0)            # the finishing pass runs on its own here
-    pipe = None if args.serial else LossyPipeline(device, split=args.split, finish_delay_us=args.finish_delay_us, one_launch=args.one_launch, workspaces=args.workspaces)
-    if pipe is not None:
+    native = not args.serial and args.one_launch and not args.py_pipeline
+    if args.serial:
+        pipe = None
+    elif native:                                     # the C ABI's pipeline: its own streams, workspaces (allocated here) and hold-off
+        pipe = NativePipeline(device, work_bytes=db.work_bytes, workspaces=args.workspaces, timing=True, hold_us=args.finish_delay_us)
+    else:
+        pipe = LossyPipeline(device, split=args.split, finish_delay_us=args.finish_delay_us, one_launch=args.one_launch, workspaces=args.workspaces)
         for k in range(args.workspaces):
             db.workspace(k)                          # allocated here, not inside the timed region
 
@@ -217,7 +223,9 @@ def main():
 
     def run(n_steps, timing=None):
         for _ in range(n_steps):
-            if pipe is not None:
+            if native:
+                pipe.submit(db, after_current_stream=False)
+            elif pipe is not None:
                 pipe.submit(db, timing=timing)
             elif timing is None:
                 db.decode_to_argb()
@@ -234,6 +242,8 @@ def main():
 
     run(max(args.warmup, 1) if pipe is not None else args.warmup)      # the streams' first use is slow: never time it
     barrier()
+    if native:
+        pipe.stats(reset=True)
     t0 = time.perf_counter()
     run(args.steps, marks)
     barrier()
@@ -272,8 +282,14 @@ def main():
             for k in range(3):
                 acc[k] += m[2 * k].elapsed_time(m[2 * k + 1])
             finish_launches += 1
-    t_recon, t_filter, t_conv = (a / len(marks) for a in acc)          # per step
-    finish_per_step = finish_launches / len(marks)
+    if native:            # HIP timing events the pipeline keeps around both launches of every step, each on the stream its kernel runs on
+        ms_mb, ms_fin, n_done = pipe.stats()
+        assert n_done == args.steps, (n_done, args.steps)
+        t_recon, t_filter, t_conv = ms_mb / n_done, ms_mb / n_done, ms_fin / n_done
+        finish_per_step = 1.0
+    else:
+        t_recon, t_filter, t_conv = (a / len(marks) for a in acc)          # per step
+        finish_per_step = finish_launches / len(marks)
     serial_ms = None
     if args.alone and pipe is not None:              # the same steps on one stream (no overlap), for reference
         db.decode_to_argb(); torch.cuda.synchronize()
@@ -339,7 +355,7 @@ def main():
                        "macroblocks_per_gpu": n_mb, "coeff_blocks_per_mb": round(batch.n_coeff_blocks / max(n_mb, 1), 3),
                        "host_parse_ms_per_image": round(1e3 * t_parse, 2),
                        "step_pipelining": "none (--serial)" if pipe is None else
-                                          ("2 HIP streams: finishing pass of step k beside the reconstruction + loop filter kernel of step k+1; 2 workspaces alternate" if args.one_launch else
+                                          (("wp_vp8_pipeline_* (C ABI): " if native else "webp_amd.device.LossyPipeline: ") + "2 HIP streams: finishing pass of step k beside the reconstruction + loop filter kernel of step k+1; %d workspaces alternate" % args.workspaces if args.one_launch else
                                            "2 HIP streams, 2 phases: finishing pass of step k (first %d %% of the frames) beside reconstruction of step k+1, "
                                            "the rest beside its loop filter; workspaces alternate" % round(100 * args.split)),
                        "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 4)},

@@ -158,7 +158,7 @@ typedef struct wp_anim_frame {
 /* Lifecycle                                                                                    */
 /* ------------------------------------------------------------------------------------------ */
 int wp_init(int device);                 /* selects the HIP device for the calling thread; fails if none */
-int wp_shutdown(void);
+int wp_shutdown(void);                   /* destroys the streams / events wp_init created (all devices); the library re-initialises on demand */
 int wp_last_error(char* buf, int cap);   /* copies the calling thread's last error message */
 int wp_device_count(void);
 /* Test hook (no counterpart in the reference): caps the number of frames the wavefront-scheduled lossy kernels take per
@@ -260,6 +260,40 @@ int wp_vp8_decode_to_argb_static_dev(int n, const wp_vp8_frame* frames_host, con
                                      const uint32_t* d_mb, const uint32_t* d_filt, const int16_t* d_coeff,
                                      uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
                                      const uint8_t* d_alpha, uint8_t* d_argb, void* stream);
+
+/* Software pipeline over successive lossy batches (no counterpart in the reference, which decodes one image per call): the
+ * memory-bound finishing pass of batch k runs on a second stream of the pipeline beside the issue-bound reconstruction +
+ * loop filter kernel of batch k+1, which is worth a quarter of a step (8.4 -> 6.4 ms per 1024 x 1080p).  The
+ * pipeline owns two HIP streams of default priority, `n_workspaces` (2..8) tile workspaces of `work_bytes` each (what
+ * wp_vp8_plan reports for the largest batch that will be submitted) and the hold-off that dispatches the persistent kernel
+ * ahead of the streaming one -- everything a caller would otherwise rebuild from INTEGRATION.md prose.
+ *   create   on the calling thread's current device.  flags: WP_PIPELINE_TIMING keeps HIP timing events around both kernels
+ *            of every step (wp_vp8_pipeline_stats).
+ *   submit   enqueues the kernel of this batch and, beside it, the finishing pass of the batch submitted before; returns
+ *            without waiting (it blocks only while three earlier steps are still incomplete).  Arguments as for
+ *            wp_vp8_decode_to_argb_dev, minus the workspace; the descriptors must have been through wp_vp8_plan /
+ *            wp_vp8_batch_layout.  frames_host is copied; every device buffer must stay valid, and its contents unchanged,
+ *            until the step is complete.  inputs_ready: a hipEvent_t the kernel waits for (the caller's upload), or NULL.
+ *            A batch's outputs are complete once a LATER flush / drain has returned (or the event logic of flush has run).
+ *   flush    enqueues the finishing pass of the last batch and makes `stream` (hipStream_t; NULL = default stream) wait
+ *            for everything submitted so far, without blocking the host.
+ *   drain    the same, and blocks until everything submitted so far is complete.
+ *   destroy  drains and frees.
+ * One thread at a time per pipeline. */
+typedef struct wp_vp8_pipeline wp_vp8_pipeline;
+#define WP_PIPELINE_TIMING 1
+int wp_vp8_pipeline_create(int n_workspaces, size_t work_bytes, int flags, wp_vp8_pipeline** out);
+int wp_vp8_pipeline_submit(wp_vp8_pipeline* p, int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
+                           const uint32_t* d_mb, const uint32_t* d_filt, const int16_t* d_coeff,
+                           uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, const uint8_t* d_alpha, uint8_t* d_argb,
+                           void* inputs_ready);
+int wp_vp8_pipeline_flush(wp_vp8_pipeline* p, void* stream);
+int wp_vp8_pipeline_drain(wp_vp8_pipeline* p);
+/* Accumulated duration (ms) of the reconstruction + loop filter launches and of the finishing launches of the steps that
+ * have completed, each measured with HIP events on the stream the kernel runs on, and their number. */
+int wp_vp8_pipeline_stats(wp_vp8_pipeline* p, double* ms_recon_filter, double* ms_finish, long* steps, int reset);
+int wp_vp8_pipeline_set_hold_us(wp_vp8_pipeline* p, int us);      /* tuning: the hold-off, default 40 */
+int wp_vp8_pipeline_destroy(wp_vp8_pipeline* p);
 
 /* VP8L inverse transform chain + RGBA->ARGB swizzle.  Replaces Transform.hx inversePredictor /
  * inverseCrossColor / inverseSubtractGreen / inverseColorIndexing, the driver loop

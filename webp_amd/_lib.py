@@ -94,6 +94,13 @@ def lib():
     L.wp_yuv420_to_argb_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.wp_vp8_decode_to_argb_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp]
     L.wp_vp8_decode_to_argb_static_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.wp_vp8_pipeline_create.argtypes = [i32, sz, i32, ctypes.POINTER(vp)]
+    L.wp_vp8_pipeline_submit.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.wp_vp8_pipeline_flush.argtypes = [vp, vp]
+    L.wp_vp8_pipeline_drain.argtypes = [vp]
+    L.wp_vp8_pipeline_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), i32]
+    L.wp_vp8_pipeline_set_hold_us.argtypes = [vp, i32]
+    L.wp_vp8_pipeline_destroy.argtypes = [vp]
     L.wp_vp8l_inverse_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, vp]
     L.wp_alpha_unfilter_dev.argtypes = [i32, vp, vp, vp, vp, vp]
     L.wp_vp8_decode_to_argb.argtypes = [i32, vp, vp, sz, vp, vp, sz, vp, vp, vp, vp, vp]

@@ -21,6 +21,7 @@ int wpk_launch_vp8_filter(int n, int cus, const wp_vp8_frame* d_frames, const ui
                           const uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream);
 int wpk_mb_wgs_per_cu(void);
 int wpk_vp8l_side_init(int dev);
+void wpk_vp8l_side_shutdown(void);
 int wpk_launch_vp8_recon_filter(int n, int cus, const wp_vp8_frame* d_frames, int use_turns, const void* d_mb, const int16_t* d_coeff,
                                 const uint32_t* d_filt, uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream);
 int wpk_launch_vp8_finish(int n, int chunks, int tile_rows, int alone, const wp_vp8_frame* d_frames, const uint8_t* d_rtiles,
@@ -251,7 +252,14 @@ int wp_init(int device) {
     return static_scratch(&sp);             // set-up is where the static workspace's address on this device is looked up
 }
 
-int wp_shutdown(void) { return WP_OK; }
+// Releases what wp_init created: the VP8L chain's side stream and its two events on every device the library was
+// initialised for.  The library re-initialises itself on the next compute call (or wp_init).  Pipelines are the caller's to
+// destroy (wp_vp8_pipeline_destroy); device memory the library allocates lives only for the duration of a host-pointer call.
+int wp_shutdown(void) {
+    wpk_vp8l_side_shutdown();
+    g_cus.store(0, std::memory_order_relaxed);      // ensure_init() runs wp_init again
+    return WP_OK;
+}
 
 int wp_debug_set_frames_per_launch(int frames) {
     if (frames < 0) return fail(WP_ERR_INVALID, "negative frame count");

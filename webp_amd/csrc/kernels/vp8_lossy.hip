@@ -6,6 +6,7 @@
 // (Running the finishing pass inside this kernel too -- each wavefront streaming out the tile rows of the band it has
 // just filtered -- was measured and dropped: 9.7 ms per 1024 x 1080p against 9.2 ms for the two launches; a single
 // wavefront cannot keep enough loads in flight, and the call it takes cost the step loop registers.)
+#include <cstdlib>
 #include "vp8_mb_band.h"
 
 namespace wpk {
@@ -23,16 +24,24 @@ constexpr int kMbWGsPerCU = WP_MB_WGS_PER_CU;
 // the finishing pass (32 each), which is what a pipelined step runs beside it.  At 113..128 only ONE fits and the step gets
 // 8 % longer although this kernel alone gets faster -- and the register allocator, which only sees that LDS caps the kernel
 // at 4 waves per SIMD anyway, uses up to 128 freely.  (The attribute counts in units of two registers on gfx90a and later.)
+// A third finishing wave per SIMD (this kernel at 104 registers, measured with a timing-only build that needs no spills
+// there) makes the step LONGER, 6.35 -> 6.98 ms: the pass then takes more issue slots from this kernel, which is the
+// step's critical path.
 #ifndef WP_MB_NUM_VGPR
 #define WP_MB_NUM_VGPR 56
 #endif
-__global__ __attribute__((amdgpu_num_vgpr(WP_MB_NUM_VGPR))) __launch_bounds__(kMbWaves * kWave, (kMbWaves * kMbWGsPerCU + 3) / 4)
+// W wavefronts per workgroup pipeline the bands of one frame: 8, two workgroups per CU.  Four-wave workgroups (four per CU,
+// WP_MB_FORCE_WAVES=4) were tried for batches with fewer frames than workgroup slots, where frames would spread more evenly
+// over the CUs (cfg 4: 300 x 720p put two eight-wave workgroups on 44 of the 256 CUs): slower, 2.11 against 1.94 ms -- a
+// frame's twelve bands then take three rounds of four instead of two of eight.
+template <int W>
+__global__ __attribute__((amdgpu_num_vgpr(WP_MB_NUM_VGPR))) __launch_bounds__(W * kWave, (kMbWaves * kMbWGsPerCU + 3) / 4)
 void vp8_mb_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, int use_turns, const uint4* __restrict__ mb,
                    const int16_t* __restrict__ coeff, const uint32_t* __restrict__ filt, uint8_t* Ep, uint8_t* Sp) {
-    __shared__ MbWaveLds lds_all[kMbWaves];
-    __shared__ uint32_t progress[kMbWaves];
+    __shared__ MbWaveLds lds_all[W];
+    __shared__ uint32_t progress[W];
     const int wave = threadIdx.x >> 6;
-    if (threadIdx.x < kMbWaves) progress[threadIdx.x] = 0;
+    if (threadIdx.x < W) progress[threadIdx.x] = 0;
     __syncthreads();
 
     uint32_t seq = 1;                   // running band number of this workgroup (identical in all its waves)
@@ -42,8 +51,8 @@ void vp8_mb_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, int us
         const int n_bands = (fr.mbh + kBandRows - 1) / kBandRows;
         for (int band = 0; band < n_bands; ++band) {
             const uint32_t q = seq + uint32_t(band);
-            if (int(q % kMbWaves) != wave) continue;
-            mb_band<kMbWaves>(fr, band, n_bands, q, q - 1, wave, progress, lds_all[wave], mb, coeff, filt, Ep, Sp);
+            if (int(q % W) != wave) continue;
+            mb_band<W>(fr, band, n_bands, q, q - 1, wave, progress, lds_all[wave], mb, coeff, filt, Ep, Sp);
         }
         seq += uint32_t(n_bands);
     }
@@ -53,9 +62,17 @@ void vp8_mb_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, int us
 
 extern "C" int wpk_launch_vp8_recon_filter(int n, int cus, const wp_vp8_frame* d_frames, int use_turns, const void* d_mb, const int16_t* d_coeff,
                                            const uint32_t* d_filt, uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream) {
-    const int grid = n < cus * wpk::kMbWGsPerCU ? n : cus * wpk::kMbWGsPerCU;
-    hipLaunchKernelGGL(wpk::vp8_mb_kernel, dim3(grid), dim3(wpk::kMbWaves * wpk::kWave), 0, stream,
-                       n, d_frames, use_turns, reinterpret_cast<const uint4*>(d_mb), d_coeff, d_filt, d_rtiles, d_stiles);
+    static const int force_w = std::getenv("WP_MB_FORCE_WAVES") ? std::atoi(std::getenv("WP_MB_FORCE_WAVES")) : 0;      // tuning switch
+    const bool small = force_w == 4;
+    if (small) {        // four-wave workgroups, four per CU: measured on cfg 4 (300 x 720p, fewer frames than workgroup slots), not the default
+        const int slots = cus * wpk::kMbWGsPerCU * 2;
+        hipLaunchKernelGGL(wpk::vp8_mb_kernel<wpk::kMbWaves / 2>, dim3(n < slots ? n : slots), dim3(wpk::kMbWaves / 2 * wpk::kWave), 0, stream,
+                           n, d_frames, use_turns, reinterpret_cast<const uint4*>(d_mb), d_coeff, d_filt, d_rtiles, d_stiles);
+    } else {
+        const int grid = n < cus * wpk::kMbWGsPerCU ? n : cus * wpk::kMbWGsPerCU;
+        hipLaunchKernelGGL(wpk::vp8_mb_kernel<wpk::kMbWaves>, dim3(grid), dim3(wpk::kMbWaves * wpk::kWave), 0, stream,
+                           n, d_frames, use_turns, reinterpret_cast<const uint4*>(d_mb), d_coeff, d_filt, d_rtiles, d_stiles);
+    }
     return int(hipGetLastError());
 }
 
@@ -72,6 +89,6 @@ extern "C" int wpk_mb_wgs_per_cu(void) { return wpk::kMbWGsPerCU; }
 // Tuning aid: resident workgroups per CU the runtime computes for the kernel (registers, LDS).
 extern "C" int wp_debug_mb_occupancy(void) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wpk::vp8_mb_kernel, wpk::kMbWaves * wpk::kWave, 0) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wpk::vp8_mb_kernel<wpk::kMbWaves>, wpk::kMbWaves * wpk::kWave, 0) != hipSuccess) return -1;
     return n;
 }

@@ -1002,6 +1002,23 @@ hipStream_t g_side[kMaxDev];
 hipEvent_t g_fork[kMaxDev], g_join[kMaxDev];
 std::mutex g_side_mutex;
 }
+// the same hold-off for the lossy pipeline (pipeline.cpp): the finishing launch waits `us` behind the persistent kernel
+extern "C" int wpk_launch_delay(int us, hipStream_t stream) {
+    hipLaunchKernelGGL(wpk::delay_kernel, dim3(1), dim3(64), 0, stream, us);
+    return int(hipGetLastError());
+}
+// wp_shutdown: the side streams and their events go; wp_init creates them again on demand
+extern "C" void wpk_vp8l_side_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    for (int d = 0; d < kMaxDev; ++d) {
+        if (!g_side[d]) continue;
+        (void)hipStreamSynchronize(g_side[d]);
+        (void)hipStreamDestroy(g_side[d]);
+        (void)hipEventDestroy(g_fork[d]);
+        (void)hipEventDestroy(g_join[d]);
+        g_side[d] = nullptr; g_fork[d] = nullptr; g_join[d] = nullptr;
+    }
+}
 extern "C" int wpk_vp8l_side_init(int dev) {
     if (dev < 0 || dev >= kMaxDev) return 0;
     std::lock_guard<std::mutex> lock(g_side_mutex);

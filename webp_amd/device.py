@@ -290,3 +290,58 @@ class LossyPipeline:
         cur.wait_stream(self.s_finish)
         self._queued.clear()
         self._phase2_done = None
+
+
+class NativePipeline:
+    """The C ABI's software pipeline (wp_vp8_pipeline_*, csrc/pipeline.cpp): what LossyPipeline(one_launch=True) does, but
+    inside the library -- its own two streams, its own workspaces, its own hold-off -- so that a caller in any language gets
+    the pipelined step.  bench.py's timed region runs through this object.
+
+    submit(db) enqueues the reconstruction + loop filter kernel of `db` and, beside it, the finishing pass of the batch
+    submitted before; drain() completes everything (host sync); flush() makes the current torch stream wait instead."""
+
+    def __init__(self, device="cuda:0", work_bytes=0, workspaces=2, timing=False, hold_us=None):
+        self.device = torch.device(device)
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().wp_vp8_pipeline_create(workspaces, work_bytes, 1 if timing else 0, ctypes.byref(self._h)))
+        if hold_us is not None:
+            check(lib().wp_vp8_pipeline_set_hold_us(self._h, int(hold_us)))
+        self._keep = []
+
+    def submit(self, db: "DeviceLossyBatch", planes=True, argb=True, after_current_stream=True):
+        """after_current_stream: the kernel waits for what has been enqueued on the current torch stream so far (uploads)."""
+        ev = None
+        if after_current_stream:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+        y, u, v = db._planes(planes)
+        check(lib().wp_vp8_pipeline_submit(self._h, db.b.n, db.b.desc, db.frames.data_ptr(), db.mb.data_ptr(), db.filt.data_ptr(),
+                                           db.coeff.data_ptr(), y, u, v, db._alpha(), db.argb.data_ptr() if argb else None,
+                                           ctypes.c_void_p(ev.cuda_event) if ev is not None else None))
+        self._keep = (self._keep + [(db, ev)])[-8:]          # buffers and the event stay alive while steps are in flight
+
+    def flush(self):
+        check(lib().wp_vp8_pipeline_flush(self._h, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def drain(self):
+        check(lib().wp_vp8_pipeline_drain(self._h))
+        self._keep = []
+
+    def stats(self, reset=False):
+        """(ms in reconstruction + loop filter launches, ms in finishing launches, completed steps) since the last reset."""
+        a, b, n = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_long(0)
+        check(lib().wp_vp8_pipeline_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n), 1 if reset else 0))
+        return a.value, b.value, n.value
+
+    def close(self):
+        if self._h:
+            lib().wp_vp8_pipeline_destroy(self._h)
+            self._h = ctypes.c_void_p()
+            self._keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
