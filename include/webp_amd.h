@@ -274,6 +274,9 @@ int wp_vp8_decode_to_argb_static_dev(int n, const wp_vp8_frame* frames_host, con
  *            wp_vp8_decode_to_argb_dev, minus the workspace; the descriptors must have been through wp_vp8_plan /
  *            wp_vp8_batch_layout.  frames_host is copied; every device buffer must stay valid, and its contents unchanged,
  *            until the step is complete.  inputs_ready: a hipEvent_t the kernel waits for (the caller's upload), or NULL.
+ *            alpha_ready: a hipEvent_t only the finishing pass waits for, or NULL -- the alpha planes are not needed before
+ *            it, so a caller can produce them (wp_vp8l_inverse_dev + wp_alpha_unfilter_dev) on a stream of its own beside
+ *            the reconstruction + loop filter kernel; both events must stay alive until the step is complete.
  *            A batch's outputs are complete once a LATER flush / drain has returned (or the event logic of flush has run).
  *   flush    enqueues the finishing pass of the last batch and makes `stream` (hipStream_t; NULL = default stream) wait
  *            for everything submitted so far, without blocking the host.
@@ -286,7 +289,7 @@ int wp_vp8_pipeline_create(int n_workspaces, size_t work_bytes, int flags, wp_vp
 int wp_vp8_pipeline_submit(wp_vp8_pipeline* p, int n, const wp_vp8_frame* frames_host, const wp_vp8_frame* d_frames,
                            const uint32_t* d_mb, const uint32_t* d_filt, const int16_t* d_coeff,
                            uint8_t* d_y, uint8_t* d_u, uint8_t* d_v, const uint8_t* d_alpha, uint8_t* d_argb,
-                           void* inputs_ready);
+                           void* inputs_ready, void* alpha_ready);
 int wp_vp8_pipeline_flush(wp_vp8_pipeline* p, void* stream);
 int wp_vp8_pipeline_drain(wp_vp8_pipeline* p);
 /* Accumulated duration (ms) of the reconstruction + loop filter launches and of the finishing launches of the steps that

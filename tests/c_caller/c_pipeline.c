@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
         HIPCHK(hipMemset(d_argb[b], 0, (size_t)sz.argb_bytes));
         if (wp_vp8_pipeline_submit(pipe, 1, &frame, (const wp_vp8_frame*)d_frame[b], (const uint32_t*)d_mb[b], (const uint32_t*)d_filt[b],
                                    (const int16_t*)d_coeff[b], (uint8_t*)d_y[b], (uint8_t*)d_u[b], (uint8_t*)d_v[b], NULL,
-                                   (uint8_t*)d_argb[b], NULL) != WP_OK) return die("wp_vp8_pipeline_submit");
+                                   (uint8_t*)d_argb[b], NULL, NULL) != WP_OK) return die("wp_vp8_pipeline_submit");
     }
     if (wp_vp8_pipeline_drain(pipe) != WP_OK) return die("wp_vp8_pipeline_drain");
 

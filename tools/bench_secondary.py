@@ -105,67 +105,95 @@ def anim_alpha(device, n=300, reps=4):
     for f in frames:
         _load_vp8l_meta(f)
         assert f.has_alpha and f.alpha_is_vp8l
-    batch = LossyBatch(frames, with_alpha=[True] * n)
-    lb = LosslessBatch(frames, alpha_image=True)
-    for i in range(n):
-        lb.desc[i].out_off = batch.desc[i].alpha_off          # the chain's green-only last pass writes the alpha slab itself
-    db = DeviceLossyBatch(batch, device, alpha=np.zeros(max(batch.alpha_bytes, 16), np.uint8))
-    d_lf = torch.from_numpy(np.frombuffer(bytes(lb.desc), dtype=np.uint8).copy()).to(device)
-    pix0 = torch.from_numpy(lb.pix).to(device); pix = torch.empty_like(pix0)
-    aux = torch.from_numpy(lb.aux).to(device)
-    tmp = torch.empty(lb.out_bytes, dtype=torch.uint8, device=device)
+    # One round by default: the whole animation as ONE device batch through the library's pipeline (wp_vp8_pipeline_*).  The
+    # alpha planes (alpha chain with the green-only last pass writing the alpha slab + unfilterAlpha in place) are needed by
+    # the finishing pass only: they are produced on a side stream from the start and the finishing pass waits for their event.
+    # What bounds the step is the latency of ONE frame: a 720p frame is a chain of 174 dependent wavefront steps and takes
+    # 0.90 ms with the GPU to itself, 0.94 ms when 256 frames run at once (one per CU) and 1.30 ms for 300 (two workgroups on
+    # 44 CUs) -- tools/mb_small_batches.py.  Rounds of one frame per CU, the finishing pass of a round beside the kernel of
+    # the next (WEBP_CFG4_ROUND=256), do not pay: 0.94 + 0.91 ms of kernels in sequence, 2.70 ms per step against 1.9.
+    from webp_amd.device import NativePipeline, pipeline_streams
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    per_round = int(os.environ.get("WEBP_CFG4_ROUND", "0")) or n
+    bounds = list(range(0, n, per_round)) + [n]
+    parts = []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        fr = frames[lo:hi]
+        m = len(fr)
+        batch = LossyBatch(fr, with_alpha=[True] * m)
+        lb = LosslessBatch(fr, alpha_image=True)
+        for i in range(m):
+            lb.desc[i].out_off = batch.desc[i].alpha_off      # the chain's green-only last pass writes the alpha slab itself
+        db = DeviceLossyBatch(batch, device, alpha=np.zeros(max(batch.alpha_bytes, 16), np.uint8))
+        adesc = (AlphaFrame * m)()                             # unfilterAlpha in place on the alpha slab
+        for i, f in enumerate(fr):
+            a = adesc[i]
+            a.width, a.height, a.filter, a.src_is_vp8l_rgba = f.alpha_width, f.alpha_height, f.alpha_filter, 0
+            a.src_off = a.dst_off = batch.desc[i].alpha_off
+        pix0 = torch.from_numpy(lb.pix).to(device)
+        parts.append(dict(lo=lo, m=m, batch=batch, lb=lb, db=db, adesc=adesc,
+                          d_lf=torch.from_numpy(np.frombuffer(bytes(lb.desc), dtype=np.uint8).copy()).to(device),
+                          d_af=torch.from_numpy(np.frombuffer(bytes(adesc), dtype=np.uint8).copy()).to(device),
+                          pix0=pix0, pix=torch.empty_like(pix0), aux=torch.from_numpy(lb.aux).to(device),
+                          tmp=torch.empty(lb.out_bytes, dtype=torch.uint8, device=device),
+                          unfilter=any(f.alpha_filter != 0 for f in fr)))
     stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-    adesc = (AlphaFrame * n)()                                 # unfilterAlpha in place on the alpha slab
-    for i, f in enumerate(frames):
-        a = adesc[i]
-        a.width, a.height, a.filter, a.src_is_vp8l_rgba = f.alpha_width, f.alpha_height, f.alpha_filter, 0
-        a.src_off = a.dst_off = batch.desc[i].alpha_off
-    d_af = torch.from_numpy(np.frombuffer(bytes(adesc), dtype=np.uint8).copy()).to(device)
-    need_unfilter = any(f.alpha_filter != 0 for f in frames)
-
-    # The alpha planes are needed by the finishing pass only: the alpha chain + unfilterAlpha run on a second stream beside
-    # the reconstruction + loop filter kernel (300 frames leave two fifths of its persistent workgroups' slots empty) and
-    # are joined before the finishing pass.
-    from webp_amd.device import pipeline_streams
     s_side = pipeline_streams(device)[1]
     side = ctypes.c_void_p(s_side.cuda_stream)
+    pipe = NativePipeline(device, work_bytes=max(p_["db"].work_bytes for p_ in parts), workspaces=2)
 
     def step():
         s_main = torch.cuda.current_stream(device)
         ev0 = torch.cuda.Event(); ev0.record(s_main)
-        db.recon_filter()
+        ready = []
         with torch.cuda.stream(s_side):
             s_side.wait_event(ev0)
-            pix.copy_(pix0)                                    # the chain consumes its input (1.2 B/px of the frame: inside the timed span here)
-            check(lib().wp_vp8l_inverse_dev(n, lb.desc, d_lf.data_ptr(), pix.data_ptr(), aux.data_ptr(), tmp.data_ptr(), db.alpha.data_ptr(), 2, side))
-            if need_unfilter:
-                check(lib().wp_alpha_unfilter_dev(n, adesc, d_af.data_ptr(), db.alpha.data_ptr(), db.alpha.data_ptr(), side))
-            ev1 = torch.cuda.Event(); ev1.record(s_side)
-        s_main.wait_event(ev1)
-        db.finish()
+            for p_ in parts:
+                p_["pix"].copy_(p_["pix0"])                    # the chain consumes its input (1.2 B/px of the frame: inside the timed span here)
+                check(lib().wp_vp8l_inverse_dev(p_["m"], p_["lb"].desc, p_["d_lf"].data_ptr(), p_["pix"].data_ptr(), p_["aux"].data_ptr(),
+                                                p_["tmp"].data_ptr(), p_["db"].alpha.data_ptr(), 2, side))
+                if p_["unfilter"]:
+                    check(lib().wp_alpha_unfilter_dev(p_["m"], p_["adesc"], p_["d_af"].data_ptr(), p_["db"].alpha.data_ptr(), p_["db"].alpha.data_ptr(), side))
+                ev = torch.cuda.Event(); ev.record(s_side)
+                ready.append(ev)
+        for p_, ev in zip(parts, ready):
+            pipe.submit(p_["db"], alpha_ready=ev)
+        pipe.flush()                                           # the current stream waits for everything
 
-    lib().wp_hint_finish_overlap(0)                            # the finishing pass runs on its own here
     ms = _timed(step, reps)
-    lib().wp_hint_finish_overlap(1)
+    pipe.drain()
     want = oracle.decode(anim)["frames"]
-    idx = sorted(set([0, 1, 2, n // 2, n - 2, n - 1]))
+    idx = sorted(set([0, 1, 2, n // 2, min(cus, n - 1), n - 2, n - 1]))
+    def part_of(i):
+        for p_ in parts:
+            if p_["lo"] <= i < p_["lo"] + p_["m"]:
+                return p_["db"], i - p_["lo"]
     for i in idx:
-        if not np.array_equal(db.argb_of(i), want[i]["to_argb"]):
+        dbi, k = part_of(i)
+        if not np.array_equal(dbi.argb_of(k), want[i]["to_argb"]):
             raise RuntimeError("frame %d of the animation (A,R,G,B with its decoded alpha) differs from the oracle" % i)
-        y, u, v = db.planes(i)
+        y, u, v = dbi.planes(k)
         if not (np.array_equal(y, want[i]["y"]) and np.array_equal(u, want[i]["u"]) and np.array_equal(v, want[i]["v"])):
             raise RuntimeError("planes of frame %d of the animation differ from the oracle" % i)
-    px = sum(batch.desc[i].width * batch.desc[i].height for i in range(n))
-    alg = batch.input_bytes() + 384 * batch.n_mb + 4 * px + px + lb.pix.size + lb.aux.size        # + alpha plane read, + the coded alpha image
+    pipe.close()
+    px = sum(p_["batch"].desc[i].width * p_["batch"].desc[i].height for p_ in parts for i in range(p_["m"]))
+    alg = sum(p_["batch"].input_bytes() + 384 * p_["batch"].n_mb + p_["lb"].pix.size + p_["lb"].aux.size for p_ in parts) + 4 * px + px        # + alpha plane read, + the coded alpha image
+    # canvas compositing wants the frames of the whole animation in one slab: gather the rounds' ARGB slabs
+    argb_all = torch.cat([p_["db"].argb[:p_["batch"].argb_bytes] for p_ in parts])
+    argb_off = []
+    base = 0
+    for p_ in parts:
+        argb_off += [base + int(p_["batch"].desc[i].argb_off) for i in range(p_["m"])]
+        base += p_["batch"].argb_bytes
     # canvas compositing of the same animation on the device: frames are where the finishing pass left them
     from webp_amd._lib import AnimFrame
     cdesc = (AnimFrame * n)()
     for i, f in enumerate(frames):
         c = cdesc[i]
-        c.x, c.y, c.width, c.height, c.blend, c.dispose, c.argb_off = f.x, f.y, f.width, f.height, int(f.blend), int(f.dispose), batch.desc[i].argb_off
+        c.x, c.y, c.width, c.height, c.blend, c.dispose, c.argb_off = f.x, f.y, f.width, f.height, int(f.blend), int(f.dispose), argb_off[i]
     d_cf = torch.from_numpy(np.frombuffer(bytes(cdesc), dtype=np.uint8).copy()).to(device)
     canvases = torch.empty(n * 4 * pf.width * pf.height, dtype=torch.uint8, device=device)
-    compose = lambda: check(lib().wp_anim_compose_dev(n, cdesc, d_cf.data_ptr(), pf.width, pf.height, db.argb.data_ptr(), canvases.data_ptr(), stream))
+    compose = lambda: check(lib().wp_anim_compose_dev(n, cdesc, d_cf.data_ptr(), pf.width, pf.height, argb_all.data_ptr(), canvases.data_ptr(), stream))
     compose_ms = _timed(compose, reps)
     k_chk = 4
     want_c = oracle.anim_compose([(w["x"], w["y_off"], w["width"], w["height"], w["blend"], w["dispose"], w["to_argb"]) for w in want[:k_chk]], pf.width, pf.height)
@@ -175,7 +203,7 @@ def anim_alpha(device, n=300, reps=4):
     compose_bytes = 4 * px + 4 * n * pf.width * pf.height
     extra_compose = {"compose_ms": round(compose_ms, 4), "compose_Mpix_s": round(n * pf.width * pf.height / compose_ms / 1e3, 1),
                      "compose_frac": round(compose_bytes / (compose_ms * 1e-3) / 8e12, 4), "compose_verified_canvases": k_chk}
-    return _record("cfg4_anim_720p_alpha", "one animated WebP (ANMF), %d frames of 1280x720 lossy + VP8L-coded ALPH (filter %d): alpha chain + unfilterAlpha (on a second stream, beside) recon + loop filter, then the finishing pass with alpha"
+    return _record("cfg4_anim_720p_alpha", "one animated WebP (ANMF), %d frames of 1280x720 lossy + VP8L-coded ALPH (filter %d): one device batch through wp_vp8_pipeline_*; alpha chain + unfilterAlpha on a side stream beside the reconstruction + loop filter kernel, awaited by the finishing pass only"
                    % (n, frames[0].alpha_filter), ms, px, alg, len(idx), host_parse_s=round(t_parse, 3), file_bytes=len(anim), **extra_compose)
 
 

@@ -23,8 +23,21 @@ def u24(v):
     return bytes((v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff))
 
 
-def build_anim(stills, n_frames: int, duration_ms: int = 33) -> bytes:
-    """stills: list of .webp byte strings (VP8X stills with ALPH + 'VP8 ', all of one size); frame k re-uses still k % len."""
+def alph_with_filter(alph: bytes, filter_id: int) -> bytes:
+    """The same ALPH chunk body with another prediction filter in its header byte (pre-processing | filter | compression,
+    WebPDecoder.hx:78-83).  The coded data stay what they are, so the plane that comes out is no longer the encoder's --
+    but it is a valid chunk, and unfilterAlpha (WebPDecoder.hx:357-411) runs the chosen filter over it."""
+    return bytes(((alph[0] & ~0x0c) | ((filter_id & 3) << 2),)) + alph[1:]
+
+
+def raw_alph(plane: bytes, filter_id: int) -> bytes:
+    """An uncompressed ALPH chunk body (compression 0, WebPDecoder.hx:313-322): header byte + width * height bytes."""
+    return bytes(((filter_id & 3) << 2,)) + bytes(plane)
+
+
+def build_anim(stills, n_frames: int, duration_ms: int = 33, alph_for=None) -> bytes:
+    """stills: list of .webp byte strings (VP8X stills with ALPH + 'VP8 ', all of one size); frame k re-uses still k % len.
+    alph_for(k, alph, w, h) -> ALPH chunk body of frame k (default: the still's own)."""
     parts = []
     for s in stills:
         c = dict(chunks(s))
@@ -40,6 +53,8 @@ def build_anim(stills, n_frames: int, duration_ms: int = 33) -> bytes:
     for k in range(n_frames):
         _, _, alph, vp8 = parts[k % len(parts)]
         frame = u24(0) + u24(0) + u24(w - 1) + u24(h - 1) + u24(duration_ms) + bytes((0x02,))      # no blend, no dispose
+        if alph_for is not None:
+            alph = alph_for(k, alph, w, h)
         if alph is not None:
             frame += _chunk(b"ALPH", alph)
         frame += _chunk(b"VP8 ", vp8)

@@ -95,7 +95,7 @@ def lib():
     L.wp_vp8_decode_to_argb_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp]
     L.wp_vp8_decode_to_argb_static_dev.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.wp_vp8_pipeline_create.argtypes = [i32, sz, i32, ctypes.POINTER(vp)]
-    L.wp_vp8_pipeline_submit.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.wp_vp8_pipeline_submit.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.wp_vp8_pipeline_flush.argtypes = [vp, vp]
     L.wp_vp8_pipeline_drain.argtypes = [vp]
     L.wp_vp8_pipeline_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), i32]

@@ -37,6 +37,7 @@ struct wp_vp8_pipeline {
         void* work = nullptr;
         uint8_t *y = nullptr, *u = nullptr, *v = nullptr, *argb = nullptr;
         const uint8_t* alpha = nullptr;
+        hipEvent_t alpha_ready = nullptr;             // caller's event: the alpha slab is complete (the finishing pass waits for it)
         hipEvent_t mb0 = nullptr, mb1 = nullptr;      // around the reconstruction + loop filter kernel (main stream)
         hipEvent_t fin0 = nullptr, fin1 = nullptr;    // around the finishing pass (finish stream); fin1 = the step's outputs are complete
     };
@@ -80,6 +81,7 @@ void retire_front(wp_vp8_pipeline* p) {
 int enqueue_finish(wp_vp8_pipeline* p, bool hold) {
     wp_vp8_pipeline::Step& s = p->pending;
     HIP_TRY(hipStreamWaitEvent(p->s_fin, s.mb1, 0));
+    if (s.alpha_ready) HIP_TRY(hipStreamWaitEvent(p->s_fin, s.alpha_ready, 0));
     if (hold && p->hold_us > 0) {
         const int e = wpk_launch_delay(p->hold_us, p->s_fin);
         if (e) return hip_fail(hipError_t(e), "hold-off launch");
@@ -137,7 +139,7 @@ int wp_vp8_pipeline_create(int n_workspaces, size_t work_bytes, int flags, wp_vp
 
 int wp_vp8_pipeline_submit(wp_vp8_pipeline* p, int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint32_t* d_mb,
                            const uint32_t* d_filt, const int16_t* d_coeff, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
-                           const uint8_t* d_alpha, uint8_t* d_argb, void* inputs_ready) {
+                           const uint8_t* d_alpha, uint8_t* d_argb, void* inputs_ready, void* alpha_ready) {
     if (!p) return fail(WP_ERR_INVALID, "null pipeline");
     if (n <= 0 || !fh || !fd) return fail(WP_ERR_INVALID, "a pipeline step needs at least one frame");
     DeviceGuard g; int rc = g.enter(p->device); if (rc) return rc;
@@ -150,6 +152,7 @@ int wp_vp8_pipeline_submit(wp_vp8_pipeline* p, int n, const wp_vp8_frame* fh, co
     wp_vp8_pipeline::Step s;
     try { s.fh.assign(fh, fh + n); } catch (const std::bad_alloc&) { return fail(WP_ERR_NOMEM, "out of memory"); }
     s.fd = fd; s.y = d_y; s.u = d_u; s.v = d_v; s.alpha = d_alpha; s.argb = d_argb;
+    s.alpha_ready = hipEvent_t(alpha_ready);
     const size_t n_ws = p->ws.size();
     s.work = p->ws[size_t(p->k % n_ws)];
     // The finishing pass that last read this workspace belongs to the step submitted n_ws steps ago.  Steps complete in

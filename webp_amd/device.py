@@ -309,8 +309,9 @@ class NativePipeline:
             check(lib().wp_vp8_pipeline_set_hold_us(self._h, int(hold_us)))
         self._keep = []
 
-    def submit(self, db: "DeviceLossyBatch", planes=True, argb=True, after_current_stream=True):
-        """after_current_stream: the kernel waits for what has been enqueued on the current torch stream so far (uploads)."""
+    def submit(self, db: "DeviceLossyBatch", planes=True, argb=True, after_current_stream=True, alpha_ready=None):
+        """after_current_stream: the kernel waits for what has been enqueued on the current torch stream so far (uploads).
+        alpha_ready: a torch.cuda.Event only the finishing pass waits for (the alpha planes, produced on another stream)."""
         ev = None
         if after_current_stream:
             ev = torch.cuda.Event()
@@ -318,8 +319,9 @@ class NativePipeline:
         y, u, v = db._planes(planes)
         check(lib().wp_vp8_pipeline_submit(self._h, db.b.n, db.b.desc, db.frames.data_ptr(), db.mb.data_ptr(), db.filt.data_ptr(),
                                            db.coeff.data_ptr(), y, u, v, db._alpha(), db.argb.data_ptr() if argb else None,
-                                           ctypes.c_void_p(ev.cuda_event) if ev is not None else None))
-        self._keep = (self._keep + [(db, ev)])[-8:]          # buffers and the event stay alive while steps are in flight
+                                           ctypes.c_void_p(ev.cuda_event) if ev is not None else None,
+                                           ctypes.c_void_p(alpha_ready.cuda_event) if alpha_ready is not None else None))
+        self._keep = (self._keep + [(db, ev, alpha_ready)])[-8:]          # buffers and the event stay alive while steps are in flight
 
     def flush(self):
         check(lib().wp_vp8_pipeline_flush(self._h, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
