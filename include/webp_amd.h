@@ -165,6 +165,10 @@ int wp_device_count(void);
  * launch, so that the split the library makes for batches beyond its band-sequence range (2^19 bands per persistent
  * workgroup, i.e. > 500 000 frames) can be exercised with a small batch.  0 restores the default. */
 int wp_debug_set_frames_per_launch(int frames);
+/* Test / tuning hook (no counterpart in the reference): the LDS ring of wp_vp8l_resolve_dev's kernel -- 4096, 8192 or 16384
+ * pixels; 0 restores the choice by batch size.  Results are identical for every ring (copies that reach further back than
+ * the ring re-read the output slab). */
+int wp_debug_set_resolve_ring(int pixels);
 /* Tuning hint (no counterpart in the reference): will wp_vp8_finish_dev / wp_vp8_finish_range_dev share the GPU with another
  * kernel of the caller (a pipelining caller runs them beside the next batch's wp_vp8_recon_filter_dev: the default, 1), or
  * run on their own (0)?  Selects how much work a workgroup of the pass takes; results are identical either way.

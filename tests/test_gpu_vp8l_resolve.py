@@ -192,3 +192,28 @@ def test_mixed_batch_of_tokenized_and_host_resolved_frames():
     for img, d in zip(decode_batch(files), datas):
         want = oracle.decode(d)
         assert np.array_equal(img.data.pix, want["argb"])
+
+
+@pytest.mark.parametrize("ring", [4096, 8192, 16384])
+def test_every_ring_size_gives_the_same_pixels(ring):
+    """The kernel's LDS ring is chosen by batch size (more images resident per CU with a smaller ring); copies that reach
+    further back than the ring, and cache fills longer than it, take the slab path.  Forced to each size in turn
+    (wp_debug_set_resolve_ring), the long-token / far-distance / period-copy streams and a real file must come out alike."""
+    from webp_amd._lib import check, lib
+    from webp_amd import parse
+    check(lib().wp_debug_set_resolve_ring(ring))
+    try:
+        rng = np.random.default_rng(500 + ring)
+        cases = []
+        for i in range(18):
+            w, h = int(rng.integers(300, 3000)), int(rng.integers(30, 120))
+            cases.append((w, h, (0, 1, 6, 11)[i % 4], _random_stream(rng, w, h, (0, 1, 6, 11)[i % 4], 1 + i % 2)))
+        for i in range(60):
+            w, h = int(rng.integers(1, 90)), int(rng.integers(1, 40))
+            cc = int(rng.integers(0, 12))
+            cases.append((w, h, cc, _random_stream(rng, w, h, cc, 0)))
+        f = parse(open(os.path.join(ROOT, "tests", "golden", "inputs", "3ll.webp"), "rb").read(), vp8l_tokens=True).frames[0]
+        cases.append((f.coded_width, f.vp8l_height, f.cc_bits, f.buf(6, np.uint32)))
+        _check(cases)
+    finally:
+        check(lib().wp_debug_set_resolve_ring(0))

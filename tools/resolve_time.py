@@ -13,6 +13,9 @@ check(L.wp_init(0))
 files = [os.path.join(ROOT, "tests/golden/inputs/3ll.webp"), os.path.join(ROOT, "tests/golden/inputs/5ll.webp")] + \
         sorted(glob.glob(os.path.join(ROOT, "bench_data", "lossless1080_*.webp")))
 copies = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+if len(sys.argv) > 2:                 # force the kernel's LDS ring: python tools/resolve_time.py 2048 4096
+    check(L.wp_debug_set_resolve_ring(int(sys.argv[2])))
+    print("ring forced to", sys.argv[2])
 for path in files:
     data = open(path, "rb").read()
     t0 = time.perf_counter(); parse(data); t1 = time.perf_counter(); pf = parse(data, vp8l_tokens=True); t2 = time.perf_counter()

@@ -82,6 +82,7 @@ def lib():
     vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     L.wp_init.argtypes = [i32]
     L.wp_debug_set_frames_per_launch.argtypes = [i32]
+    L.wp_debug_set_resolve_ring.argtypes = [i32]
     L.wp_hint_finish_overlap.argtypes = [i32]
     L.wp_last_error.argtypes = [ctypes.c_char_p, i32]
     L.wp_vp8_plan.argtypes = [i32, vp, ctypes.POINTER(ctypes.c_uint64)]

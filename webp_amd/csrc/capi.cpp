@@ -22,6 +22,7 @@ int wpk_launch_vp8_filter(int n, int cus, const wp_vp8_frame* d_frames, const ui
 int wpk_mb_wgs_per_cu(void);
 int wpk_vp8l_side_init(int dev);
 void wpk_vp8l_side_shutdown(void);
+void wpk_resolve_force_ring(int px);
 int wpk_launch_vp8_recon_filter(int n, int cus, const wp_vp8_frame* d_frames, int use_turns, const void* d_mb, const int16_t* d_coeff,
                                 const uint32_t* d_filt, uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream);
 int wpk_launch_vp8_finish(int n, int chunks, int tile_rows, int alone, const wp_vp8_frame* d_frames, const uint8_t* d_rtiles,
@@ -34,7 +35,7 @@ int wpk_launch_yuv420_to_argb(int n, int grid_x, const wp_vp8_frame* d_frames, c
 int wpk_launch_vp8l(int n, const wp_vp8l_frame* frames_host, const wp_vp8l_frame* d_frames, uint8_t* d_pix, const uint8_t* d_aux,
                     uint8_t* d_tmp, uint8_t* d_out, int swizzle, hipStream_t stream);
 int wpk_launch_anim_compose(int n, const wp_anim_frame* d_frames, int cw, int ch, const uint8_t* d_argb, uint8_t* d_canvases, hipStream_t stream);
-int wpk_launch_vp8l_resolve(int n, const wp_vp8l_tokens_frame* d_frames, const uint32_t* d_tokens, uint8_t* d_pix, hipStream_t stream);
+int wpk_launch_vp8l_resolve(int n, int max_cc_bits, int cus, const wp_vp8l_tokens_frame* d_frames, const uint32_t* d_tokens, uint8_t* d_pix, hipStream_t stream);
 int wpk_launch_alpha(int n, const wp_alpha_frame* frames_host, const wp_alpha_frame* d_frames, const uint8_t* d_src, uint8_t* d_alpha,
                      hipStream_t stream);
 }
@@ -264,6 +265,12 @@ int wp_shutdown(void) {
 int wp_debug_set_frames_per_launch(int frames) {
     if (frames < 0) return fail(WP_ERR_INVALID, "negative frame count");
     g_launch_cap.store(frames, std::memory_order_relaxed);
+    return WP_OK;
+}
+
+int wp_debug_set_resolve_ring(int pixels) {
+    if (pixels != 0 && pixels != 4096 && pixels != 8192 && pixels != 16384) return fail(WP_ERR_INVALID, "ring sizes: 4096, 8192, 16384 (0 = choose by batch size)");
+    wpk_resolve_force_ring(pixels);
     return WP_OK;
 }
 
@@ -512,7 +519,9 @@ int wp_vp8l_resolve_dev(int n, const wp_vp8l_tokens_frame* fh, const wp_vp8l_tok
     for (int i = 0; i < n; ++i)
         if (bad_tokens_frame(fh[i])) return fail(WP_ERR_INVALID, "bad wp_vp8l_tokens_frame at index " + std::to_string(i));
     if (n == 0) return WP_OK;
-    const int e = wpk_launch_vp8l_resolve(n, fd, d_tokens, d_pix, hipStream_t(stream));
+    int max_cc = 0;
+    for (int i = 0; i < n; ++i) max_cc = std::max(max_cc, fh[i].cc_bits);
+    const int e = wpk_launch_vp8l_resolve(n, max_cc, g_cus.load(std::memory_order_relaxed), fd, d_tokens, d_pix, hipStream_t(stream));
     if (e) return hip_fail(hipError_t(e), "vp8l resolve launch");
     return WP_OK;
 }

@@ -315,7 +315,7 @@ constexpr int kPredPublishPx = WP_PRED_PUBLISH_PX;
 
 __global__ __launch_bounds__(kPredWaves * kWave)
 void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frames, int pass, uint8_t* pix, uint8_t* tmp,
-                           const uint8_t* __restrict__ aux, uint8_t* out, int swizzle) {
+                           const uint8_t* __restrict__ aux, uint8_t* out, int swizzle, uint32_t* bands_done) {
     __shared__ uint32_t progress[kPredWaves];
 #ifndef WP_PRED_NO_STAGE
     // Final pixels leave through LDS: a lane produces 32 bytes of ITS row per step, so direct stores put 64 quarter cache
@@ -766,6 +766,8 @@ void vp8l_predictor_kernel(int n_frames, const wp_vp8l_frame* __restrict__ frame
                 }
             }
             if (has_below && pending_publish) publish_progress(&progress[wave], pending_publish);      // the band's last rows are out
+            // how far the pass has got, for the launcher's side stream (hold_until_kernel): one count per finished band
+            if (bands_done && r == 0) __hip_atomic_fetch_add(bands_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         seq += uint32_t(n_bands);
     }
@@ -974,32 +976,43 @@ int grid_for(long long items, int n_frames) {
 // Without a side stream (wp_init never ran for the device), or with one group only, the passes run one after the other as
 // before.  The enqueue sequence is short and guarded, so that the fork / join events of concurrent callers do not interleave.
 // The predictor pass is a chain of dependent steps per frame, and towards its end most of a frame's wavefronts have run out
-// of bands: the other group's streaming kernels cost least there.  So the side stream is held back for a share of the
-// predictor pass's estimated duration (steps of its longest frame x the measured time of a step x rounds of 1024 frames);
-// 1024 x 1080p, 683 of them with a predictor (estimate 3.9 ms, measured alone 4.0): held back 40 us 4.91 ms, 0.4 of the
-// estimate 4.83, 0.5 4.73, 0.6 4.63, 0.75 4.73, 0.85 4.91; no side stream 5.39; streaming kernels placed first 6.1.  An
-// estimate that is off costs a few per cent either way.
-#ifndef WP_VP8L_SIDE_DELAY_US
-#define WP_VP8L_SIDE_DELAY_US 40            // at least
-#endif
-#ifndef WP_VP8L_SIDE_DELAY_SHARE
-#define WP_VP8L_SIDE_DELAY_SHARE 0.6
-#endif
-#ifndef WP_VP8L_STEP_NS
-#define WP_VP8L_STEP_NS 2600                // one predictor step (8 pixels of 64 rows) with 3 - 4 wavefronts per SIMD
+// of bands: the other group's streaming kernels cost least there.  So the side stream is held back until a share of the
+// predictor pass's bands is done -- the pass counts them (a relaxed agent-scope add per band) and a one-wavefront kernel on
+// the side stream polls the count.  Round 2 held the stream for 0.6 x an estimate of the pass's duration (steps of its
+// longest frame x 2.6 us per step x rounds of 1024 frames): right on this GPU at this clock, 1024 x 1080p with 683 predictor
+// frames: held back 40 us 4.91 ms, 0.4 of the estimate 4.83, 0.5 4.73, 0.6 4.63, 0.75 4.73, 0.85 4.91; no side stream 5.39;
+// streaming kernels placed first 6.1.  The share of BANDS that corresponds is measured in DESIGN.md 4.4.
+#ifndef WP_VP8L_SIDE_SHARE
+#define WP_VP8L_SIDE_SHARE 0.65             // the side stream starts when this share of the predictor pass's bands is done
 #endif
 namespace wpk {
-// Holds a stream back for about `us` microseconds (one wavefront): the persistent predictor kernel has to be placed on the
-// CUs before the streaming kernels of the other group fill them, or its workgroups trickle in as those drain.
+// Holds a stream back for about `us` microseconds (one wavefront): the persistent kernel of the other stream has to be placed
+// on the CUs before streaming kernels fill them, or its workgroups trickle in as those drain (lossy pipeline, pipeline.cpp).
 __global__ void delay_kernel(int us) {
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(32);      // 100 MHz counter
+}
+// Holds a stream back until the predictor pass on the other stream has finished `target` of its bands (the counter its
+// wavefronts bump) -- PROGRESS, not a time estimate: round 2 held the side stream for 0.6 x (steps of the longest frame x
+// 2.6 us), a constant of this GPU at this clock.  Every wait ends: the kernel gives up after `max_us` whatever the counter
+// says (a faulted or never-launched predictor pass must not leave a spinning wavefront behind).
+__global__ void hold_until_kernel(const uint32_t* counter, uint32_t target, int min_us, int max_us) {
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        const unsigned long long dt = wall_clock64() - t0;
+        if (dt >= (unsigned long long)max_us * 100ull) break;
+        if (dt >= (unsigned long long)min_us * 100ull && __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
 }
 }
 namespace {
 constexpr int kMaxDev = 64;
 hipStream_t g_side[kMaxDev];
 hipEvent_t g_fork[kMaxDev], g_join[kMaxDev];
+constexpr int kCounters = 64;               // band counters handed out round-robin: a call's counter is not re-used before 63 later calls on the device
+uint32_t* g_counters[kMaxDev];
+unsigned g_next_counter[kMaxDev];
 std::mutex g_side_mutex;
 }
 // the same hold-off for the lossy pipeline (pipeline.cpp): the finishing launch waits `us` behind the persistent kernel
@@ -1016,7 +1029,8 @@ extern "C" void wpk_vp8l_side_shutdown(void) {
         (void)hipStreamDestroy(g_side[d]);
         (void)hipEventDestroy(g_fork[d]);
         (void)hipEventDestroy(g_join[d]);
-        g_side[d] = nullptr; g_fork[d] = nullptr; g_join[d] = nullptr;
+        if (g_counters[d]) (void)hipFree(g_counters[d]);
+        g_side[d] = nullptr; g_fork[d] = nullptr; g_join[d] = nullptr; g_counters[d] = nullptr;
     }
 }
 extern "C" int wpk_vp8l_side_init(int dev) {
@@ -1029,7 +1043,12 @@ extern "C" int wpk_vp8l_side_init(int dev) {
         (void)hipStreamDestroy(s);
         return int(hipGetLastError());
     }
-    g_fork[dev] = a; g_join[dev] = b; g_side[dev] = s;
+    uint32_t* c = nullptr;
+    if (hipMalloc(&c, kCounters * sizeof(uint32_t)) != hipSuccess || hipMemset(c, 0, kCounters * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipStreamDestroy(s); (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        return int(hipGetLastError());
+    }
+    g_fork[dev] = a; g_join[dev] = b; g_side[dev] = s; g_counters[dev] = c;
     return 0;
 }
 
@@ -1051,40 +1070,38 @@ extern "C" int wpk_launch_vp8l(int n, const wp_vp8l_frame* fh, const wp_vp8l_fra
         const wp_vp8l_frame* fdc = fd + first;
         const int gx = grid_for(max_px, cnt);
         bool any_p = false, any_s = false;
-        long long px = 0, pred_steps = 0;
-        int n_pred = 0;
+        long long px = 0;
         for (int i = first; i < first + cnt; ++i) {
-            if (with_predictor(i)) {
-                any_p = true;
-                ++n_pred;
-                const long long bands = (fh[i].height + kPredRows - 1) / kPredRows;
-                pred_steps = std::max(pred_steps, (bands + kPredWaves - 1) / kPredWaves * ((fh[i].width + kPC - 1) / kPC + kPredRows - 1));
-            } else {
-                any_s = true;
-            }
+            if (with_predictor(i)) any_p = true; else any_s = true;
             px += (long long)fh[i].width * fh[i].height;
         }
-        const double pred_us = double(pred_steps) * WP_VP8L_STEP_NS * 1e-3 * ((n_pred + 1023) / 1024);
-        const int delay_us = int(std::min(20000.0, std::max(double(WP_VP8L_SIDE_DELAY_US), WP_VP8L_SIDE_DELAY_SHARE * pred_us)));
-        // two streams pay for themselves on large batches only: the second one is held back 40 us (see delay_kernel)
+        // two streams pay for themselves on large batches only
 #ifdef WP_VP8L_NO_FORK                     // tuning builds: one stream whatever the batch
         const bool fork = false;
 #else
         const bool fork = have_side && any_p && any_s && px >= (64LL << 20);
 #endif
+        uint32_t* counter = nullptr;        // bands the first predictor launch has finished (fork only)
+        long long counted_bands = 0;
         // the chains of group `only` (0: every frame) on stream st
         auto chains = [&](int only, hipStream_t st) {
+            bool counted = false;
             for (int pass = 0; pass < WP_VP8L_MAX_TRANSFORMS; ++pass) {
                 bool have[4] = {false, false, false, false};
+                long long bands = 0;
                 for (int i = first; i < first + cnt; ++i) {
                     if (only && with_predictor(i) != (only == 1)) continue;
                     const int idx = fh[i].n_transforms - 1 - pass;
                     if (idx >= 0) have[fh[i].t[idx].type] = true;
+                    if (idx >= 0 && fh[i].t[idx].type == 0) bands += (fh[i].height + kPredRows - 1) / kPredRows;
                 }
                 const int arg = pass | (only << 8);
-                if (have[0])
+                if (have[0]) {
+                    uint32_t* c = (only == 1 && counter && !counted) ? counter : nullptr;      // the pass the side stream keys on
+                    if (c) { counted = true; counted_bands = bands; }
                     hipLaunchKernelGGL(vp8l_predictor_kernel, dim3(std::min(cnt, 1024)), dim3(kPredWaves * kWave), 0, st,
-                                       cnt, fdc, pass, d_pix, d_tmp, d_aux, d_out, swizzle);
+                                       cnt, fdc, pass, d_pix, d_tmp, d_aux, d_out, swizzle, c);
+                }
                 if (have[1]) hipLaunchKernelGGL(vp8l_cross_color_kernel, dim3(gx, cnt), dim3(256), 0, st, fdc, arg, d_pix, d_tmp, d_aux);
                 if (have[2]) hipLaunchKernelGGL(vp8l_subtract_green_kernel, dim3(gx, cnt), dim3(256), 0, st, fdc, arg, d_pix, d_tmp, swizzle);
                 if (have[3]) hipLaunchKernelGGL(vp8l_color_indexing_kernel, dim3(gx, cnt), dim3(256), 0, st, fdc, arg, d_pix, d_tmp, d_aux, d_out, swizzle);
@@ -1093,9 +1110,15 @@ extern "C" int wpk_launch_vp8l(int n, const wp_vp8l_frame* fh, const wp_vp8l_fra
         };
         if (fork) {
             hipStream_t side = g_side[dev];
+            counter = g_counters[dev] + (g_next_counter[dev]++ % kCounters);
+            // zeroed on the main stream BEFORE the fork event: the side stream's hold kernel then never sees an old count
+            if (hipMemsetAsync(counter, 0, sizeof(uint32_t), stream) != hipSuccess) return int(hipGetLastError());
             if (hipEventRecord(g_fork[dev], stream) != hipSuccess || hipStreamWaitEvent(side, g_fork[dev], 0) != hipSuccess) return int(hipGetLastError());
             chains(1, stream);
-            hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, side, delay_us);
+            // at least 40 us (the persistent predictor kernel is placed first), then until WP_VP8L_SIDE_SHARE of the pass's
+            // bands are done, at most 20 ms
+            const uint32_t target = uint32_t(std::max(1.0, WP_VP8L_SIDE_SHARE * double(counted_bands)));
+            hipLaunchKernelGGL(hold_until_kernel, dim3(1), dim3(64), 0, side, counter, target, 40, 20000);
             chains(2, side);
             if (hipEventRecord(g_join[dev], side) != hipSuccess || hipStreamWaitEvent(stream, g_join[dev], 0) != hipSuccess) return int(hipGetLastError());
         } else {

@@ -13,17 +13,24 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
+#include <atomic>
 #include "../../../include/webp_amd.h"
 
 namespace wpk {
 
-constexpr uint32_t kRingPx = 16384, kRingMask = kRingPx - 1;
-constexpr uint32_t kCopyPiece = 4096;                       // the longest copy the bitstream can code (Vp8LDecoder.hx:337-345); longer ones are taken in pieces
-constexpr uint32_t kRingReach = kRingPx - kCopyPiece - 64;  // copies up to this distance never see a ring slot reused under them
 constexpr int kMaxCacheBits = 11;                           // Vp8LDecoder.hx:228
-// LDS budget: 64 KiB ring + two 8 KiB cache arrays = 80 KiB per wavefront.  That is a gfx950 budget (160 KiB per CU: two
-// images resident per CU); the library is built for gfx950 only (Makefile ARCH), and a 64 KiB-LDS part could not hold it.
-static_assert((kRingPx + 2u * (1u << kMaxCacheBits)) * 4u <= 160u * 1024u / 2u, "vp8l_resolve_kernel: two wavefronts' LDS must fit gfx950's 160 KiB per CU");
+// The ring is a template parameter: 16384 pixels (64 KiB) serve every distance code for images up to 1746 pixels wide but
+// leave room for two images per CU -- two of its four SIMDs then idle, the other two hold one wavefront each, and the loop
+// is a chain of ~480-cycle tokens.  8192 / 4096 pixels (32 / 16 KiB) admit four / eight images per CU; copies that reach
+// further back than the ring take the slab path (a release fence and loads from L2), which photo-like streams rarely need.
+// The launcher picks the ring from the batch size (enough images to fill the CUs at that residency) -- LDS per wavefront =
+// ring + the two colour-cache arrays, sized by the largest cache of the batch (dynamic LDS).  gfx950 only (160 KiB per CU).
+template <uint32_t kRingPx> struct RingCfg {
+    static constexpr uint32_t kMask = kRingPx - 1;
+    static constexpr uint32_t kPiece = kRingPx >= 16384 ? 4096 : kRingPx / 8;      // longest stretch copied before the ring position is re-examined (4096 = the longest copy the bitstream codes, Vp8LDecoder.hx:337-345)
+    static constexpr uint32_t kReach = kRingPx - kPiece - 64;                      // copies up to this distance never see a ring slot reused under them
+};
+static_assert(16384u * 4u + 2u * (4u << kMaxCacheBits) <= 160u * 1024u / 2u, "vp8l_resolve_kernel: two wavefronts with the largest ring and cache must fit gfx950's 160 KiB per CU");
 
 __device__ __forceinline__ uint32_t lane_word(uint32_t v, uint32_t l) { return uint32_t(__builtin_amdgcn_readlane(int(v), int(l))); }
 __device__ __forceinline__ uint32_t far_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -33,11 +40,14 @@ __device__ __forceinline__ uint32_t cache_hash(uint32_t rgba) {
     return argb * 0x1e35a7bdu;
 }
 
+template <uint32_t kRingPx>
 __global__ __launch_bounds__(64)
-void vp8l_resolve_kernel(const wp_vp8l_tokens_frame* __restrict__ frames, const uint32_t* __restrict__ tokens, uint8_t* pix_slab) {
+void vp8l_resolve_kernel(const wp_vp8l_tokens_frame* __restrict__ frames, const uint32_t* __restrict__ tokens, uint8_t* pix_slab, int cache_entries) {
+    constexpr uint32_t kRingMask = RingCfg<kRingPx>::kMask, kCopyPiece = RingCfg<kRingPx>::kPiece, kRingReach = RingCfg<kRingPx>::kReach;
     __shared__ uint32_t ring[kRingPx];
-    __shared__ uint32_t cval[1 << kMaxCacheBits];
-    __shared__ uint32_t cown[1 << kMaxCacheBits];           // 1 + index of the pixel that owns the entry
+    extern __shared__ uint32_t cache_lds[];                 // 2 x cache_entries words: values, then 1 + index of the pixel that owns the entry
+    uint32_t* const cval = cache_lds;
+    uint32_t* const cown = cache_lds + cache_entries;
     const wp_vp8l_tokens_frame fr = frames[blockIdx.x];
     const uint32_t lane = threadIdx.x;
     const uint32_t* tok = tokens + (fr.tok_off >> 2);
@@ -185,7 +195,18 @@ void vp8l_resolve_kernel(const wp_vp8l_tokens_frame* __restrict__ frames, const 
 
 }  // namespace wpk
 
-extern "C" int wpk_launch_vp8l_resolve(int n, const wp_vp8l_tokens_frame* d_frames, const uint32_t* d_tokens, uint8_t* d_pix, hipStream_t stream) {
-    hipLaunchKernelGGL(wpk::vp8l_resolve_kernel, dim3(n), dim3(64), 0, stream, d_frames, d_tokens, d_pix);
+namespace { std::atomic<int> g_force_ring{0}; }
+extern "C" void wpk_resolve_force_ring(int px) { g_force_ring.store(px, std::memory_order_relaxed); }
+// max_cc_bits: the largest colour-cache size (bits) among the frames; cus: compute units of the device
+extern "C" int wpk_launch_vp8l_resolve(int n, int max_cc_bits, int cus, const wp_vp8l_tokens_frame* d_frames, const uint32_t* d_tokens, uint8_t* d_pix, hipStream_t stream) {
+    const int entries = max_cc_bits > 0 ? 1 << max_cc_bits : 0;
+    const size_t dyn = size_t(2) * size_t(entries) * 4;
+    const int force = g_force_ring.load(std::memory_order_relaxed);      // wp_debug_set_resolve_ring: test hook
+    // enough images to give every SIMD a wavefront (or two) at the smaller rings?  otherwise the big ring costs nothing
+    int ring = n >= 6 * cus ? 4096 : n >= 3 * cus ? 8192 : 16384;
+    if (force == 4096 || force == 8192 || force == 16384) ring = force;
+    if (ring == 4096) hipLaunchKernelGGL(wpk::vp8l_resolve_kernel<4096>, dim3(n), dim3(64), dyn, stream, d_frames, d_tokens, d_pix, entries);
+    else if (ring == 8192) hipLaunchKernelGGL(wpk::vp8l_resolve_kernel<8192>, dim3(n), dim3(64), dyn, stream, d_frames, d_tokens, d_pix, entries);
+    else hipLaunchKernelGGL(wpk::vp8l_resolve_kernel<16384>, dim3(n), dim3(64), dyn, stream, d_frames, d_tokens, d_pix, entries);
     return int(hipGetLastError());
 }
