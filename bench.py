@@ -316,7 +316,7 @@ def main():
     # (tools/pmc.sh + tools/pmc_traffic.list), committed under profiles/; scaled if --images differs from that run.
     traffic = None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json" if args.one_launch else "r01_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json" if args.one_launch else "r01_traffic.json")))
         traffic = int(tj["kernels"][dom]["hbm_bytes"] * args.images / tj["images_per_launch"] / launches)
     except Exception:
         pass

@@ -207,7 +207,7 @@ def anim_alpha(device, n=300, reps=4):
                    % (n, frames[0].alpha_filter), ms, px, alg, len(idx), host_parse_s=round(t_parse, 3), file_bytes=len(anim), **extra_compose)
 
 
-def vp8l_resolve(device, n=512):
+def vp8l_resolve(device, n=2048):
     """decodePix's pixel loop on the device (first slice): n copies of a photo-like lossless stream's tokens."""
     import numpy as np
     import torch

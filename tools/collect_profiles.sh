@@ -36,6 +36,7 @@ python3 tools/prof_summary.py $(find $out/kt_alpha -name "*results.db" | head -1
 run 300 rocprofv3 --kernel-trace --stats -d $out/kt_lossless -o ll -- python3 tools/lossless_times.py 1024 > $out/kt_lossless.log 2>&1
 python3 tools/prof_summary.py $(find $out/kt_lossless -name "*results.db" | head -1) $out/lossless_kernel_stats.txt > /dev/null
 run 200 python3 tools/resolve_time.py 512 > $out/resolve_time.txt 2>&1
+run 200 python3 tools/resolve_time.py 2048 > $out/resolve_time_2048.txt 2>&1
 [ -x tools/ubench/valu_rate_fp ] && run 100 ./tools/ubench/valu_rate_fp > $out/ubench_valu_rate_fp.txt 2>&1
 # the raw databases are large and not needed once summarised
 find $out -name "*results.db" -delete

@@ -11,5 +11,6 @@ cp $(find $src/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) profile
 cp $(find $src/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) profiles/${tag}_pmc_write_size.csv
 cp $(find $src/pmc_sq -name "*counter_collection.csv" | head -1) profiles/${tag}_pmc_sq_insts.csv
 cp $(find $src/pmc_lds -name "*counter_collection.csv" | head -1) profiles/${tag}_pmc_lds.csv
-cp $src/traffic.json profiles/r02_traffic.json
+cp $src/traffic.json profiles/r03_traffic.json
+cp $src/resolve_time_2048.txt profiles/${tag}_resolve_time_2048.txt
 ls -la profiles/${tag}_*

@@ -59,6 +59,11 @@ void vp8l_resolve_kernel(const wp_vp8l_tokens_frame* __restrict__ frames, const 
     for (uint32_t i = lane; i < cc_size; i += 64) { cval[i] = 0; cown[i] = 0; }
 
     uint32_t pos = 0, p = 0, cached = 0;
+    // Pixels [0, fenced) are known to have reached L2: the slab path (copies and cache fills that reach further back than the
+    // ring) reads this wavefront's own earlier stores, and only a release fence -- a wait for every store still in flight --
+    // makes them visible to its loads.  What the slab path reads is at least a ring's reach old, so one fence serves every
+    // far access of the next few thousand pixels (a photo-like 300 x 300 stream: 568 far copies, ~30 fences).
+    uint32_t fenced = 0;
     // (settle: the wait for a token block's load sits where the block is loaded.  Left to the compiler it sits in front of
     // every token's v_readlane, as s_waitcnt vmcnt(0) -- which also waits for every pixel store of the token before.)
     uint32_t blk_base = 0, blk = lane < n_words ? tok[lane] : 0u;
@@ -145,7 +150,7 @@ void vp8l_resolve_kernel(const wp_vp8l_tokens_frame* __restrict__ frames, const 
                         }
                     }
                 } else {                                     // dist > kRingReach > l: plain forward copy out of the slab
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (src0 + l > fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); fenced = p; }
                     for (uint32_t c = 0; c < l; c += 64) {
                         const uint32_t i = c + lane;
                         if (i < l) {
@@ -162,6 +167,9 @@ void vp8l_resolve_kernel(const wp_vp8l_tokens_frame* __restrict__ frames, const 
         } else if (kind == WP_TOK_CACHE) {
             if (arg >= cc_size) break;                        // "Invalid color cache index" / "null color cache"
             // the pixels written since the last lookup enter the cache now, in order (Vp8LDecoder.hx:320-327)
+            // pixels that have left the ring come back from the slab: ONE release fence makes this wavefront's own stores
+            // visible to its loads (nothing is stored between here and the end of the fill)
+            if (p - cached > kRingPx && p - kRingPx > fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); fenced = p; }
             for (uint32_t b = cached; b < p; b += 64) {
                 const uint32_t idx = b + lane;
                 const bool active = idx < p;
@@ -169,7 +177,6 @@ void vp8l_resolve_kernel(const wp_vp8l_tokens_frame* __restrict__ frames, const 
                 if (p - b <= kRingPx) {
                     if (active) w = ring[idx & kRingMask];
                 } else {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     uint32_t wf = 0;
                     if (active) wf = far_load(out + idx);
                     asm volatile("; settle %0" : "+v"(wf));       // (see above: keeps s_waitcnt vmcnt(0) out of the common path)
