@@ -16,12 +16,19 @@ namespace wpk {
 #define WP_FINISH_PER_WG 4
 #endif
 constexpr int kFinishPerWgShared = WP_FINISH_PER_WG;      // chunks per workgroup when the pass shares the GPU (see the kernel)
+#ifndef WP_FINISH_FAST
+#define WP_FINISH_FAST 1
+#endif
 #ifndef WP_FINISH_PRIO
 #define WP_FINISH_PRIO 1
 #endif
 
+// 32 registers: two wavefronts per SIMD fit beside four of vp8_mb_kernel (112 each); the attribute counts in units of 2
+#ifndef WP_FINISH_NUM_VGPR
+#define WP_FINISH_NUM_VGPR 16
+#endif
 template <int kFinishPerWg>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(WP_FINISH_NUM_VGPR)))
 void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* __restrict__ Rp, const uint8_t* __restrict__ Sp,
                        int force_unshifted, uint8_t* Yp, uint8_t* Up, uint8_t* Vp, const uint8_t* __restrict__ Ap, uint8_t* out) {
     __shared__ uint4 tiles4[kFinishLdsBytes / 16];
@@ -69,7 +76,8 @@ void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* _
             nx_nt = fs.nt;
         }
         __builtin_amdgcn_sched_barrier(0);
-        finish_emit(fr, ty, c0, tt, nt, tiles4, shifted, Yp, Up, Vp, Ap, out);
+        if (!(WP_FINISH_FAST && finish_is_interior(fr, ty, c0, shifted, Yp, Up, Vp, Ap, out) && finish_emit_interior(fr, ty, c0, tt, tiles4, shifted, Yp, Up, Vp, out)))
+            finish_emit(fr, ty, c0, tt, nt, tiles4, shifted, Yp, Up, Vp, Ap, out);
         __builtin_amdgcn_sched_barrier(0);
     }
 }

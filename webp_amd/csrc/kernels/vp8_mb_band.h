@@ -49,6 +49,10 @@ namespace wpk {
 // macroblock's first block is wanted again two steps later, and with the hint that second half came from HBM again
 // (PMC: FETCH_SIZE 5.03 -> 4.35 GB per 1024 x 1080p, the step 0.4 % shorter).
 constexpr bool kCoeffNt = WP_COEFF_NT != 0;
+#ifndef WP_FILTER_F32
+#define WP_FILTER_F32 1
+#endif
+constexpr bool kFilterF32 = WP_FILTER_F32 != 0;      // the normal loop filter's mask and filter value in fp32 (vp8_filter_band.h: normal_edge_f)
 constexpr int kEdgeBytes = 32;      // per MB of a band's last row: 16 Y + 8 Cb + 8 Cr bytes of its unfiltered bottom row
 
 struct alignas(16) MbFilterTile {
@@ -330,6 +334,7 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
             const bool last_row = g == rows_here - 1;               // its bottom rows leave the band through memory
             const int level = int(fp & 0xff), ilevel = int((fp >> 8) & 0xff), hlevel = int((fp >> 16) & 0xff);
             const bool inner = (fp >> 24) & 1;
+            const float level_f = float(fp & 0xff), ilevel_f = float((fp >> 8) & 0xff), hlevel_f = float((fp >> 16) & 0xff);   // v_cvt_f32_ubyteN
             const bool do_filter = act && level != 0;                   // `if (f.level == 0) continue` (:421, :449)
             const int cb = 16 * (x & 1), pb = 16 - cb;                  // luma column base of this MB's slot / the previous MB's
             const int cb8 = cb >> 1, pb8 = pb >> 1;
@@ -357,7 +362,24 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
                 uint8_t* cr = T.c[1 + lr];
                 const int cc = lp ? 20 : 4;
                 uint2 wc = make_uint2(tile32(cr, cc), tile32(cr, cc + 4));
-                if (ftype != 0 && do_filter) {
+                if (kFilterF32 && ftype == 2 && do_filter) {
+                    {
+                        uint32_t v[20];
+                        unpack4f(t32(&F.y[4 + l][pb + 12]), v);
+                        unpack4f(w.x, v + 4); unpack4f(w.y, v + 8); unpack4f(w.z, v + 12); unpack4f(w.w, v + 16);
+                        filter_line_f<20>(v, x > 0, inner, level_f, ilevel_f, hlevel_f);
+                        t32(&F.y[4 + l][pb + 12]) = pack4f(v);
+                        w = make_uint4(pack4f(v + 4), pack4f(v + 8), pack4f(v + 12), pack4f(v + 16));
+                    }
+                    {
+                        uint32_t v[12];
+                        unpack4f(t32(&F.c[lp][4 + lr][pb8 + 4]), v);
+                        unpack4f(wc.x, v + 4); unpack4f(wc.y, v + 8);
+                        filter_line_f<12>(v, x > 0, inner, level_f, ilevel_f, hlevel_f);
+                        t32(&F.c[lp][4 + lr][pb8 + 4]) = pack4f(v);
+                        wc = make_uint2(pack4f(v + 4), pack4f(v + 8));
+                    }
+                } else if (ftype != 0 && do_filter) {
                     {
                         int v[20];
                         unpack4(t32(&F.y[4 + l][pb + 12]), v);
@@ -384,7 +406,25 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
             if (ftype != 0) {
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_setprio(WP_MB_PRIO_H);
-                if (do_filter) {
+                if (kFilterF32 && ftype == 2 && do_filter) {
+                    // ---- horizontal edges: lane = pixel column; rows -4..15 relative to the MB ----
+                    {
+                        uint32_t v[20];
+#pragma unroll
+                        for (int k = 0; k < 20; ++k) v[k] = uint32_t(F.y[k][cb + l]) | kFBias;
+                        filter_line_f<20>(v, y > 0, inner, level_f, ilevel_f, hlevel_f);
+#pragma unroll
+                        for (int k = 1; k < 19; ++k) F.y[k][cb + l] = uint8_t(v[k]);
+                    }
+                    {
+                        uint32_t v[12];
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) v[k] = uint32_t(F.c[lp][k][cb8 + lr]) | kFBias;
+                        filter_line_f<12>(v, y > 0, inner, level_f, ilevel_f, hlevel_f);
+#pragma unroll
+                        for (int k = 1; k < 11; ++k) F.c[lp][k][cb8 + lr] = uint8_t(v[k]);
+                    }
+                } else if (do_filter) {
                     // ---- horizontal edges: lane = pixel column; rows -4..15 relative to the MB ----
                     {
                         int v[20];

@@ -61,6 +61,33 @@ __device__ __forceinline__ uint4 convert_row4_packed(uint32_t y4, const ChromaTe
     return make_uint4(__builtin_amdgcn_perm(gb_lo, ar_lo, 0x05040100u), __builtin_amdgcn_perm(gb_lo, ar_lo, 0x07060302u),
                       __builtin_amdgcn_perm(gb_hi, ar_hi, 0x05040100u), __builtin_amdgcn_perm(gb_hi, ar_hi, 0x07060302u));
 }
+// Opaque pixels, no tie: pixel-major.  A chroma sample's terms are kept as two int16 pairs, (255, r) and (g, b); a pixel is
+// two packed adds of its luma value -- broadcast to both halves by the instruction's operand selects, from whichever half of
+// y02 / y13 holds it -- and two saturating packs, the second writing the upper half of the result (255 + Y saturates to the
+// opaque alpha byte): 8 four-cycle instructions per pixel and no byte transposes, 39 half-cost units per 4 pixels against 49.
+struct ChromaPairs { uint32_t ar, gb; };
+__device__ __forceinline__ ChromaPairs chroma_pairs(const ChromaTerms& t) {
+    ChromaPairs p;
+    p.ar = (uint32_t(t.r) << 16) | 255u;
+    p.gb = __builtin_amdgcn_perm(uint32_t(t.b), uint32_t(t.g), 0x05040100u);
+    return p;
+}
+template <int HALF>      // which half of `ypair` holds this pixel's luma value
+__device__ __forceinline__ uint32_t convert_px_opaque(uint32_t ypair, const ChromaPairs& c) {
+    uint32_t lo, hi;
+    if (HALF == 0) {
+        asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(lo) : "v"(ypair), "v"(c.ar));
+        asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(hi) : "v"(ypair), "v"(c.gb));
+    } else {
+        asm("v_pk_add_u16 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(lo) : "v"(ypair), "v"(c.ar));
+        asm("v_pk_add_u16 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(hi) : "v"(ypair), "v"(c.gb));
+    }
+    return clip_pack_seq(as_s2(lo), as_s2(hi));
+}
+__device__ __forceinline__ uint4 convert_row4_opaque(uint32_t y4, const ChromaPairs& c0, const ChromaPairs& c1) {
+    const uint32_t y02 = y4 & 0x00ff00ffu, y13 = (y4 >> 8) & 0x00ff00ffu;
+    return make_uint4(convert_px_opaque<0>(y02, c0), convert_px_opaque<0>(y13, c0), convert_px_opaque<1>(y02, c1), convert_px_opaque<1>(y13, c1));
+}
 __device__ __forceinline__ uint4 convert_row4(uint32_t y4, const ChromaTerms& t0, const ChromaTerms& t1, uint32_t a4, bool any_tie) {
     return any_tie ? convert_row4<true>(y4, t0, t1, a4) : convert_row4_packed(y4, t0, t1, a4);
 }
