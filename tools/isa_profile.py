@@ -83,8 +83,9 @@ def main():
         print(f"  {f:28s} {n:6d} {by_file_cost[f]:7d}")
     print(f"  {'total':28s} {sum(by_file.values()):6d} {sum(by_file_cost.values()):7d}")
     print("== other instruction kinds:", {k[1]: v for k, v in other.items() if k[0] == "*"})
-    print("== VALU per line (top 60)")
-    for (f, l), n in sorted(per_line.items(), key=lambda kv: -kv[1])[:60]:
+    topn = int(__import__("os").environ.get("ISA_TOP", "60"))
+    print("== VALU per line (top %d)" % topn)
+    for (f, l), n in sorted(per_line.items(), key=lambda kv: -kv[1])[:topn]:
         print(f"  {f}:{l:<5d} {n:5d} {per_line_cost[(f, l)]:6d}")
     print("== opcodes (top 40)")
     for o, n in ops.most_common(40):

@@ -124,6 +124,9 @@ __device__ __forceinline__ void filter_line(int (&v)[N], bool mb_edge, bool inne
 // is one v_med3_f32 and one fma; adding 1.5 * 2^23 turns it into an integer in the mantissa, and from there the deltas are
 // the integer code of normal_edge, applied to the samples' bit patterns with integer adds and clamped between the bit
 // patterns of 2^23 + 0 and 2^23 + 255.  Measured against normal_edge: 50 against 61 half-cost units per inner edge.
+#ifndef WP_EDGE_SKIP
+#define WP_EDGE_SKIP 0      // measured: q90 stream 7.27 -> 6.94 ms, q75 4.98 -> 5.05, mixed pipelined step unchanged within noise: off
+#endif
 constexpr uint32_t kFBias = 0x4B000000u;                 // 2^23
 constexpr uint32_t kFMagicBits = 0x4B400000u;            // 1.5 * 2^23
 __device__ __forceinline__ float fsample(uint32_t bits) { return __uint_as_float(bits); }
@@ -158,6 +161,9 @@ __device__ __forceinline__ void normal_edge_f(uint32_t p3, uint32_t& p2, uint32_
     const float m10 = fmax_abs2(d10, e01);
     const float worst = fmax_abs3(e12, e23, fmax_abs3(d32, d21, m10));
     const bool on = use & (fma_abs4(e0, d1) <= thr) & (worst <= ilevel);
+#if WP_EDGE_SKIP
+    if (__builtin_amdgcn_ballot_w64(on) == 0) return;      // no lane of the wavefront filters this edge
+#endif
     const bool hev = m10 > hlevel;
     const float outer = __builtin_amdgcn_fmed3f(d1, -127.0f, 127.0f);
     if (FOUR) {
