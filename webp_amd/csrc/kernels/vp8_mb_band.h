@@ -384,12 +384,12 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
                         int v[20];
                         unpack4(t32(&F.y[4 + l][pb + 12]), v);
                         unpack4(w.x, v + 4); unpack4(w.y, v + 8); unpack4(w.z, v + 12); unpack4(w.w, v + 16);
-                        if (ftype == 1) filter_line<20, true>(v, x > 0, inner, level, ilevel, hlevel);
+                        if (kFilterF32 || ftype == 1) filter_line<20, true>(v, x > 0, inner, level, ilevel, hlevel);      // (with the fp32 edges only the simple filter gets here)
                         else filter_line<20, false>(v, x > 0, inner, level, ilevel, hlevel);
                         t32(&F.y[4 + l][pb + 12]) = pack4i(v);
                         w = make_uint4(pack4i(v + 4), pack4i(v + 8), pack4i(v + 12), pack4i(v + 16));
                     }
-                    if (ftype == 2) {
+                    if (!kFilterF32 && ftype == 2) {
                         int v[12];
                         unpack4(t32(&F.c[lp][4 + lr][pb8 + 4]), v);
                         unpack4(wc.x, v + 4); unpack4(wc.y, v + 8);
@@ -430,12 +430,12 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
                         int v[20];
 #pragma unroll
                         for (int k = 0; k < 20; ++k) v[k] = F.y[k][cb + l];
-                        if (ftype == 1) filter_line<20, true>(v, y > 0, inner, level, ilevel, hlevel);
+                        if (kFilterF32 || ftype == 1) filter_line<20, true>(v, y > 0, inner, level, ilevel, hlevel);
                         else filter_line<20, false>(v, y > 0, inner, level, ilevel, hlevel);
 #pragma unroll
                         for (int k = 1; k < 19; ++k) F.y[k][cb + l] = uint8_t(v[k]);
                     }
-                    if (ftype == 2) {
+                    if (!kFilterF32 && ftype == 2) {
                         int v[12];
 #pragma unroll
                         for (int k = 0; k < 12; ++k) v[k] = F.c[lp][k][cb8 + lr];
