@@ -10,6 +10,17 @@
 
 // Everything this pass touches is used exactly once: non-temporal accesses keep it out of the way of the tiles and
 // coefficient blocks that the wavefront-scheduled code re-reads through L2.
+// timing-only builds: the pass without its plane stores / without its ARGB stores (how much of a pipelined step is HBM time)
+#ifdef WP_KO_PLANES
+#define WP_PLANE_STORE(p, v) asm volatile("" :: "v"(v))
+#else
+#define WP_PLANE_STORE(p, v) WP_NT_STORE(p, v)
+#endif
+#ifdef WP_KO_ARGB
+#define WP_ARGB_STORE(p, v) asm volatile("" :: "v"(v))
+#else
+#define WP_ARGB_STORE(p, v) WP_NT_STORE(p, v)
+#endif
 #ifdef WP_FINISH_NO_NT
 #define WP_NT_LOAD(p) (*(p))
 #define WP_NT_STORE(p, v) (*(p) = (v))
@@ -153,18 +164,18 @@ __device__ __forceinline__ bool finish_emit_interior(const wp_vp8_frame& fr, int
         const uint32_t ya = tiles32[lbase], yb = tiles32[lbase + 4];
         uint8_t* const Yrow = Yp + fr.y_off + size_t(row0 * ystride + uint32_t(c0));
         const uint32_t yo = __umul24(2u * rp, ystride) + 4u * q;
-        WP_NT_STORE(reinterpret_cast<uint32_t*>(Yrow + yo), ya);
-        WP_NT_STORE(reinterpret_cast<uint32_t*>(Yrow + ystride + yo), yb);
+        WP_PLANE_STORE(reinterpret_cast<uint32_t*>(Yrow + yo), ya);
+        WP_PLANE_STORE(reinterpret_cast<uint32_t*>(Yrow + ystride + yo), yb);
         uint8_t* const Arow = out + fr.argb_off + 4u * size_t(row0 * width + uint32_t(c0));
         const uint32_t po = 4u * (__umul24(2u * rp, width) + 4u * q);
         __builtin_amdgcn_sched_barrier(0);      // one row at a time: interleaved, the two conversions need 38 registers (budget: 32)
         const uint4 o0 = convert_row4_opaque(ya, cp0, cp1);
         const u32x4 w0 = {o0.x, o0.y, o0.z, o0.w};
-        WP_NT_STORE(reinterpret_cast<u32x4*>(Arow + po), w0);
+        WP_ARGB_STORE(reinterpret_cast<u32x4*>(Arow + po), w0);
         __builtin_amdgcn_sched_barrier(0);
         const uint4 o1 = convert_row4_opaque(yb, cp0, cp1);
         const u32x4 w1 = {o1.x, o1.y, o1.z, o1.w};
-        WP_NT_STORE(reinterpret_cast<u32x4*>(Arow + 4u * width + po), w1);
+        WP_ARGB_STORE(reinterpret_cast<u32x4*>(Arow + 4u * width + po), w1);
     }
     __builtin_amdgcn_sched_barrier(0);
     {
@@ -172,7 +183,7 @@ __device__ __forceinline__ bool finish_emit_interior(const wp_vp8_frame& fr, int
         const uint32_t row = (uint32_t(t) >> 4) & 7u, dw = uint32_t(t) & 15u;
         const uint32_t cs = 4u * dw + (shift >> 1);
         uint8_t* const P = (plane ? Vp + fr.v_off : Up + fr.u_off) + size_t(((row0 >> 1)) * cstride + (uint32_t(c0) >> 1));
-        WP_NT_STORE(reinterpret_cast<uint32_t*>(P + (__umul24(row, cstride) + 4u * dw)),
+        WP_PLANE_STORE(reinterpret_cast<uint32_t*>(P + (__umul24(row, cstride) + 4u * dw)),
                     tiles32[(cs >> 3) * uint32_t(kTileBytes / 4) + uint32_t(kTileCb / 4) + 16u * plane + 2u * row + ((cs >> 2) & 1u)]);
     }
     return true;
