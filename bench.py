@@ -152,7 +152,7 @@ def main():
                     "0 = every rank decodes --images images (weak scaling, the default)")
     ap.add_argument("--serial", action="store_true", help="one stream per step, no overlap between steps (kernel times as when each runs alone)")
     ap.add_argument("--split", type=float, default=0.6, help="share of a step's frames whose finishing pass runs beside the next reconstruction (the rest: beside the next loop filter)")
-    ap.add_argument("--finish-delay-us", type=float, default=40.0, help="how long a finishing pass is held back so that the persistent kernel of its phase is dispatched first")
+    ap.add_argument("--finish-delay-us", type=float, default=15.0, help="how long a finishing pass is held back so that the persistent kernel of its phase is dispatched first")
     ap.add_argument("--two-phase", action="store_true", help="round-1 schedule: reconstruction and loop filter as two kernels (R tiles through HBM), the finishing pass of the step before split over both")
     ap.add_argument("--py-pipeline", action="store_true", help="pipeline the steps with webp_amd.device.LossyPipeline (torch streams, torch.cuda._sleep as hold-off) instead of the library's own wp_vp8_pipeline_* (the default)")
     ap.add_argument("--workspaces", type=int, default=2, help="tile workspaces the pipelined steps rotate through")

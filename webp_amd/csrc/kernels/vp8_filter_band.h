@@ -145,14 +145,26 @@ __device__ __forceinline__ float fma_abs4(float a, float b) {                // 
     asm("v_fma_f32 %0, |%1|, 4.0, |%2|" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ int f_to_int(float a) {                           // a: an integer of magnitude < 2^22
-    return int(__float_as_uint(a + __uint_as_float(kFMagicBits)) - kFMagicBits);
+// DEN = the denormal domain: a sample x is the float whose bit pattern is the integer x itself, x * 2^-149.  Kernels are
+// compiled with fp32 denormals preserved (.amdhsa_float_denorm_mode_32 3; add / fma / max / med3 / compare run at full rate
+// on them), differences and 4A + B are still exact, thresholds are the record's integers as they are, and samples need no bias
+// going in (byte loads, unpacked dwords) or out.  Signed results (the filter value) are sign-magnitude bit patterns: adding
+// 2048 * 2^-149 first makes them positive, and the integer is the bit pattern minus 2048.
+constexpr uint32_t kDenMagicBits = 0x00000800u;
+template <bool DEN>
+__device__ __forceinline__ int f_to_int(float a) {                           // a: an integer (times 2^-149 if DEN) of magnitude < 2048
+    constexpr uint32_t m = DEN ? kDenMagicBits : kFMagicBits;
+    return int(__float_as_uint(a + __uint_as_float(m)) - m);
 }
-__device__ __forceinline__ uint32_t fclamp255(uint32_t bits) { return uint32_t(clampi(int(bits), int(kFBias), int(kFBias + 255u))); }
+template <bool DEN>
+__device__ __forceinline__ uint32_t fclamp255(uint32_t bits) {
+    constexpr uint32_t b = DEN ? 0u : kFBias;
+    return uint32_t(clampi(int(bits), int(b), int(b + 255u)));
+}
 
 // Differences are written in position order, so that the one an edge shares with the next edge of the line (its q2 - q3 is
 // the next one's p1 - p0 when neither sample changed) is computed once by common-subexpression elimination.
-template <bool FOUR>
+template <bool FOUR, bool DEN = false>
 __device__ __forceinline__ void normal_edge_f(uint32_t p3, uint32_t& p2, uint32_t& p1, uint32_t& p0, uint32_t& q0, uint32_t& q1, uint32_t& q2, uint32_t q3,
                                               float thr, float ilevel, float hlevel, bool use) {
     const float d32 = fsample(p3) - fsample(p2), d21 = fsample(p2) - fsample(p1), d10 = fsample(p1) - fsample(p0);
@@ -165,32 +177,33 @@ __device__ __forceinline__ void normal_edge_f(uint32_t p3, uint32_t& p2, uint32_
     if (__builtin_amdgcn_ballot_w64(on) == 0) return;      // no lane of the wavefront filters this edge
 #endif
     const bool hev = m10 > hlevel;
-    const float outer = __builtin_amdgcn_fmed3f(d1, -127.0f, 127.0f);
+    const float lim = DEN ? __uint_as_float(127u) : 127.0f;
+    const float outer = __builtin_amdgcn_fmed3f(d1, -lim, lim);
     if (FOUR) {
         const float af = __builtin_fmaf(e0, 3.0f, hev ? outer : 0.0f);
-        const int a = f_to_int(on ? af : 0.0f);
+        const int a = f_to_int<DEN>(on ? af : 0.0f);
         const int a1 = clamp15((a + 4) >> 3);
         const int a2 = clamp15((a + 3) >> 3);
         const int a3 = hev ? 0 : (a1 + 1) >> 1;
-        p1 = fclamp255(p1 + uint32_t(a3));
-        p0 = fclamp255(p0 + uint32_t(a2));
-        q0 = fclamp255(q0 - uint32_t(a1));
-        q1 = fclamp255(q1 - uint32_t(a3));
+        p1 = fclamp255<DEN>(p1 + uint32_t(a3));
+        p0 = fclamp255<DEN>(p0 + uint32_t(a2));
+        q0 = fclamp255<DEN>(q0 - uint32_t(a1));
+        q1 = fclamp255<DEN>(q1 - uint32_t(a3));
     } else {
         const float wf = __builtin_fmaf(e0, 3.0f, outer);
-        const int w = f_to_int(on ? wf : 0.0f);
+        const int w = f_to_int<DEN>(on ? wf : 0.0f);
         const int a = clamp127(w);
         const int c1 = (__mul24(a, 27) + 63) >> 7, c2 = (__mul24(a, 18) + 63) >> 7, c3 = (__mul24(a, 9) + 63) >> 7;
         const int dp0 = hev ? clamp15((w + 3) >> 3) : c1;
         const int dq0 = hev ? clamp15((w + 4) >> 3) : c1;
         const int dd1 = hev ? 0 : c2;
         const int dd2 = hev ? 0 : c3;
-        p2 = fclamp255(p2 + uint32_t(dd2));
-        p1 = fclamp255(p1 + uint32_t(dd1));
-        p0 = fclamp255(p0 + uint32_t(dp0));
-        q0 = fclamp255(q0 - uint32_t(dq0));
-        q1 = fclamp255(q1 - uint32_t(dd1));
-        q2 = fclamp255(q2 - uint32_t(dd2));
+        p2 = fclamp255<DEN>(p2 + uint32_t(dd2));
+        p1 = fclamp255<DEN>(p1 + uint32_t(dd1));
+        p0 = fclamp255<DEN>(p0 + uint32_t(dp0));
+        q0 = fclamp255<DEN>(q0 - uint32_t(dq0));
+        q1 = fclamp255<DEN>(q1 - uint32_t(dd1));
+        q2 = fclamp255<DEN>(q2 - uint32_t(dd2));
     }
 }
 
@@ -205,6 +218,20 @@ __device__ __forceinline__ void filter_line_f(uint32_t (&v)[N], bool mb_edge, bo
         normal_edge_f<true>(v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19], thr, ilevel_f, hlevel_f, inner);
     }
 }
+// the same in the denormal domain: v[] holds plain integers 0..255, level / ilevel / hlevel are the record's bytes
+template <int N>
+__device__ __forceinline__ void filter_line_d(uint32_t (&v)[N], bool mb_edge, bool inner, int level, int ilevel, int hlevel) {
+    const float thr = __uint_as_float(uint32_t(2 * level + 1)), thr_mb = __uint_as_float(uint32_t(2 * level + 9));
+    const float il = __uint_as_float(uint32_t(ilevel)), hl = __uint_as_float(uint32_t(hlevel));
+    normal_edge_f<false, true>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], thr_mb, il, hl, mb_edge);
+    normal_edge_f<true, true>(v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], thr, il, hl, inner);
+    if constexpr (N == 20) {
+        normal_edge_f<true, true>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], thr, il, hl, inner);
+        normal_edge_f<true, true>(v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19], thr, il, hl, inner);
+    }
+}
+__device__ __forceinline__ void unpack4u(uint32_t w, uint32_t* v) { v[0] = w & 0xff; v[1] = (w >> 8) & 0xff; v[2] = (w >> 16) & 0xff; v[3] = w >> 24; }
+__device__ __forceinline__ uint32_t pack4u(const uint32_t* v) { return v[0] | v[1] << 8 | v[2] << 16 | v[3] << 24; }
 // bytes of a dword -> four biased samples, and back (the clamped bit patterns carry the sample in their low byte)
 __device__ __forceinline__ void unpack4f(uint32_t w, uint32_t* v) {
     v[0] = __builtin_amdgcn_perm(kFBias, w, 0x070c0c00u); v[1] = __builtin_amdgcn_perm(kFBias, w, 0x070c0c01u);

@@ -8,6 +8,19 @@
 // on 128-byte boundaries of the row (no cache line is shared between workgroups).  Frames are read from the S tiles (shift 8 luma /
 // 4 chroma: what the loop filter and the one-kernel path leave, also for frames whose loop filter is off) or, on request,
 // from the R tiles (no shift: the unfiltered planes wp_vp8_recon_dev can return).
+#ifndef WP_FINISH_PRIO
+#define WP_FINISH_PRIO 1
+#endif
+// Interior chunks drop to priority 0 after their first row of pixels (WP_FINISH_LO_AT 1).  The two kernels of a pipelined
+// step share the SIMDs' issue slots, their stretched durations add up to what those allow (~11 ms per 1024 x 1080p), and a
+// step is as long as the longer of the two: at 1 throughout the pass takes 4.6 ms and vp8_mb_kernel 6.4; at 0 throughout 5.9 /
+// 5.1; dropping after parking (LO_AT 0) 5.85 / 5.2, after the second row (2) 5.35 / 5.8; after the first row 5.44 / 5.51 ms.
+#ifndef WP_FINISH_PRIO_LO
+#define WP_FINISH_PRIO_LO 0
+#endif
+#ifndef WP_FINISH_LO_AT
+#define WP_FINISH_LO_AT 1
+#endif
 #include "vp8_finish_chunk.h"
 
 namespace wpk {
@@ -47,6 +60,35 @@ void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* _
     const int ty = blockIdx.y, c_first = blockIdx.x * (kFinishPerWg * kFinishCols);
     const int c_end = 16 * fr.mbw;
     if (ty >= fr.mbh + (shifted ? 1 : 0) || c_first >= c_end) return;
+    // Two loops, chosen per workgroup (its chunks are neighbours in one tile row, so only the one at the ragged right edge
+    // differs from the rest): all chunks interior -> the predicate-free path (vp8_finish_chunk.h), else the general path for all
+    // of them.  One loop that chose per chunk held both paths' state at once: 38 registers.
+    // Measured and not kept: interior chunks without workgroup barriers (every wavefront fetching and parking just the 54
+    // 16-byte pieces of the tiles that its own four luma rows and two chroma rows need).  The pass gets faster beside the
+    // reconstruction kernel (5.63 -> 4.56 ms stretched) and slows that kernel by as much (5.69 -> 6.86 ms; at issue priority 0:
+    // 5.52 / 6.26 ms): the sum of the two is what the SIMDs' issue slots allow, and a step is 6.4 - 7.0 ms against 5.8.
+    const int n_here = min(kFinishPerWg, (c_end - c_first + kFinishCols - 1) / kFinishCols);
+    if (WP_FINISH_FAST && finish_is_interior(fr, ty, c_first + (n_here - 1) * kFinishCols, shifted, Yp, Up, Vp, Ap, out)) {
+        u32x4 nx = finish_fetch(finish_src(fr, ty, c_first, Rp, Sp, shifted), t);
+#pragma unroll
+        for (int i = 0; i < kFinishPerWg; ++i) {
+            const int c0 = c_first + i * kFinishCols;
+            if (i >= n_here) break;
+            if (i) __syncthreads();                           // the chunk before has been read out of LDS
+            int tt = t;
+            asm volatile("" : "+v"(tt));                      // (thread roles re-derived per chunk from an opaque copy: see below)
+#if WP_FINISH_PRIO_LO != WP_FINISH_PRIO
+            if (i) __builtin_amdgcn_s_setprio(WP_FINISH_PRIO);
+#endif
+            if (tt < kFinishTiles * (kTileBytes / 16)) tiles4[tt] = make_uint4(nx.x, nx.y, nx.z, nx.w);
+            __syncthreads();
+            if (i + 1 < n_here) nx = finish_fetch(finish_src(fr, ty, c0 + kFinishCols, Rp, Sp, shifted), tt);
+            __builtin_amdgcn_sched_barrier(0);
+            finish_emit_interior(fr, ty, c0, tt, tiles4, shifted, Yp, Up, Vp, out);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
     // kFinishPerWg adjacent chunks per workgroup, the next chunk's tiles fetched into registers while the current one is
     // converted.  Built to test whether the pass, of which a CU holds only two workgroups beside the one-kernel
     // reconstruction + loop filter, is bound there by the latency of its one load per workgroup: hardly -- at issue priority 0
@@ -76,8 +118,7 @@ void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* _
             nx_nt = fs.nt;
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (!(WP_FINISH_FAST && finish_is_interior(fr, ty, c0, shifted, Yp, Up, Vp, Ap, out) && finish_emit_interior(fr, ty, c0, tt, tiles4, shifted, Yp, Up, Vp, out)))
-            finish_emit(fr, ty, c0, tt, nt, tiles4, shifted, Yp, Up, Vp, Ap, out);
+        finish_emit(fr, ty, c0, tt, nt, tiles4, shifted, Yp, Up, Vp, Ap, out);
         __builtin_amdgcn_sched_barrier(0);
     }
 }

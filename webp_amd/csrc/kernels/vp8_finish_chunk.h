@@ -137,13 +137,13 @@ __device__ __forceinline__ void finish_emit(const wp_vp8_frame& fr, int ty, int 
 __device__ __forceinline__ bool finish_is_interior(const wp_vp8_frame& fr, int ty, int c0, bool shifted, const uint8_t* Yp, const uint8_t* Up,
                                                    const uint8_t* Vp, const uint8_t* Ap, const uint8_t* out) {
     const int row0 = 16 * ty - (shifted ? kFiltShift : 0);
-    return Yp != nullptr && Up != nullptr && Vp != nullptr && out != nullptr && !(Ap != nullptr && fr.has_alpha) && row0 >= 0 &&
+    return shifted && Yp != nullptr && Up != nullptr && Vp != nullptr && out != nullptr && !(Ap != nullptr && fr.has_alpha) && row0 >= 0 &&
            row0 + 16 <= fr.height && c0 + kFinishCols <= fr.width && (fr.width & 3) == 0 &&
            ((reinterpret_cast<uintptr_t>(out) + fr.argb_off) & 15) == 0;
 }
-// Returns false, having written nothing, when a lane of the wavefront holds the chroma pair whose green term needs the
-// Y-dependent tie correction (wp_convert.h): the caller then takes the general path, and this one carries no code for it.
-__device__ __forceinline__ bool finish_emit_interior(const wp_vp8_frame& fr, int ty, int c0, int t, const uint4* tiles4, bool shifted,
+// A wavefront that holds the chroma pair whose green term needs the Y-dependent tie correction (wp_convert.h) takes the
+// conversion with the correction for the chunk (a wavefront-uniform branch).
+__device__ __forceinline__ void finish_emit_interior(const wp_vp8_frame& fr, int ty, int c0, int t, const uint4* tiles4, bool shifted,
                                                      uint8_t* Yp, uint8_t* Up, uint8_t* Vp, uint8_t* out) {
     const uint32_t* tiles32 = reinterpret_cast<const uint32_t*>(tiles4);
     const uint16_t* tiles16 = reinterpret_cast<const uint16_t*>(tiles4);
@@ -157,9 +157,12 @@ __device__ __forceinline__ bool finish_emit_interior(const wp_vp8_frame& fr, int
         const uint32_t lbase = k * uint32_t(kTileBytes / 4) + sub + 8u * rp;
         const uint32_t ci = k * uint32_t(kTileBytes / 2) + 4u * rp + sub;
         const uint32_t u2 = tiles16[ci + kTileCb / 2], v2 = tiles16[ci + kTileCr / 2];
+#if WP_FINISH_PRIO_LO != WP_FINISH_PRIO && WP_FINISH_LO_AT == 0
+        __builtin_amdgcn_s_setprio(WP_FINISH_PRIO_LO);
+#endif
         const ChromaTerms t0 = chroma_terms(int(u2 & 0xff), int(v2 & 0xff));
         const ChromaTerms t1 = chroma_terms(int(u2 >> 8), int(v2 >> 8));
-        if (__builtin_amdgcn_ballot_w64(t0.tie || t1.tie) != 0) return false;
+        const bool any_tie = __builtin_amdgcn_ballot_w64(t0.tie || t1.tie) != 0;
         const ChromaPairs cp0 = chroma_pairs(t0), cp1 = chroma_pairs(t1);
         const uint32_t ya = tiles32[lbase], yb = tiles32[lbase + 4];
         uint8_t* const Yrow = Yp + fr.y_off + size_t(row0 * ystride + uint32_t(c0));
@@ -169,13 +172,21 @@ __device__ __forceinline__ bool finish_emit_interior(const wp_vp8_frame& fr, int
         uint8_t* const Arow = out + fr.argb_off + 4u * size_t(row0 * width + uint32_t(c0));
         const uint32_t po = 4u * (__umul24(2u * rp, width) + 4u * q);
         __builtin_amdgcn_sched_barrier(0);      // one row at a time: interleaved, the two conversions need 38 registers (budget: 32)
-        const uint4 o0 = convert_row4_opaque(ya, cp0, cp1);
+        uint4 o0 = convert_row4_opaque(ya, cp0, cp1);
+        if (any_tie) tie_patch_row4(o0, ya, t0.tie, t1.tie);
         const u32x4 w0 = {o0.x, o0.y, o0.z, o0.w};
         WP_ARGB_STORE(reinterpret_cast<u32x4*>(Arow + po), w0);
+#if WP_FINISH_PRIO_LO != WP_FINISH_PRIO && WP_FINISH_LO_AT == 1
+        __builtin_amdgcn_s_setprio(WP_FINISH_PRIO_LO);       // the second half of a chunk at the lower priority (see vp8_finish.hip)
+#endif
         __builtin_amdgcn_sched_barrier(0);
-        const uint4 o1 = convert_row4_opaque(yb, cp0, cp1);
+        uint4 o1 = convert_row4_opaque(yb, cp0, cp1);
+        if (any_tie) tie_patch_row4(o1, yb, t0.tie, t1.tie);
         const u32x4 w1 = {o1.x, o1.y, o1.z, o1.w};
         WP_ARGB_STORE(reinterpret_cast<u32x4*>(Arow + 4u * width + po), w1);
+#if WP_FINISH_PRIO_LO != WP_FINISH_PRIO && WP_FINISH_LO_AT == 2
+        __builtin_amdgcn_s_setprio(WP_FINISH_PRIO_LO);
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     {
@@ -186,7 +197,6 @@ __device__ __forceinline__ bool finish_emit_interior(const wp_vp8_frame& fr, int
         WP_PLANE_STORE(reinterpret_cast<uint32_t*>(P + (__umul24(row, cstride) + 4u * dw)),
                     tiles32[(cs >> 3) * uint32_t(kTileBytes / 4) + uint32_t(kTileCb / 4) + 16u * plane + 2u * row + ((cs >> 2) & 1u)]);
     }
-    return true;
 }
 
 }  // namespace wpk

@@ -50,8 +50,9 @@ namespace wpk {
 // (PMC: FETCH_SIZE 5.03 -> 4.35 GB per 1024 x 1080p, the step 0.4 % shorter).
 constexpr bool kCoeffNt = WP_COEFF_NT != 0;
 #ifndef WP_FILTER_F32
-#define WP_FILTER_F32 1
+#define WP_FILTER_F32 2      // 0: integer edges, 1: fp32 on 2^23 + x, 2: fp32 on denormals (vp8_filter_band.h); 5.45 / 5.15 / 4.99 ms per 1024 x 1080p alone
 #endif
+constexpr bool kFilterDen = WP_FILTER_F32 == 2;      // ... with the samples as fp32 denormals (plain integers as bit patterns) instead of 2^23 + x
 constexpr bool kFilterF32 = WP_FILTER_F32 != 0;      // the normal loop filter's mask and filter value in fp32 (vp8_filter_band.h: normal_edge_f)
 constexpr int kEdgeBytes = 32;      // per MB of a band's last row: 16 Y + 8 Cb + 8 Cr bytes of its unfiltered bottom row
 
@@ -365,19 +366,35 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
                 if (kFilterF32 && ftype == 2 && do_filter) {
                     {
                         uint32_t v[20];
-                        unpack4f(t32(&F.y[4 + l][pb + 12]), v);
-                        unpack4f(w.x, v + 4); unpack4f(w.y, v + 8); unpack4f(w.z, v + 12); unpack4f(w.w, v + 16);
-                        filter_line_f<20>(v, x > 0, inner, level_f, ilevel_f, hlevel_f);
-                        t32(&F.y[4 + l][pb + 12]) = pack4f(v);
-                        w = make_uint4(pack4f(v + 4), pack4f(v + 8), pack4f(v + 12), pack4f(v + 16));
+                        if constexpr (kFilterDen) {
+                            unpack4u(t32(&F.y[4 + l][pb + 12]), v);
+                            unpack4u(w.x, v + 4); unpack4u(w.y, v + 8); unpack4u(w.z, v + 12); unpack4u(w.w, v + 16);
+                            filter_line_d<20>(v, x > 0, inner, level, ilevel, hlevel);
+                            t32(&F.y[4 + l][pb + 12]) = pack4u(v);
+                            w = make_uint4(pack4u(v + 4), pack4u(v + 8), pack4u(v + 12), pack4u(v + 16));
+                        } else {
+                            unpack4f(t32(&F.y[4 + l][pb + 12]), v);
+                            unpack4f(w.x, v + 4); unpack4f(w.y, v + 8); unpack4f(w.z, v + 12); unpack4f(w.w, v + 16);
+                            filter_line_f<20>(v, x > 0, inner, level_f, ilevel_f, hlevel_f);
+                            t32(&F.y[4 + l][pb + 12]) = pack4f(v);
+                            w = make_uint4(pack4f(v + 4), pack4f(v + 8), pack4f(v + 12), pack4f(v + 16));
+                        }
                     }
                     {
                         uint32_t v[12];
-                        unpack4f(t32(&F.c[lp][4 + lr][pb8 + 4]), v);
-                        unpack4f(wc.x, v + 4); unpack4f(wc.y, v + 8);
-                        filter_line_f<12>(v, x > 0, inner, level_f, ilevel_f, hlevel_f);
-                        t32(&F.c[lp][4 + lr][pb8 + 4]) = pack4f(v);
-                        wc = make_uint2(pack4f(v + 4), pack4f(v + 8));
+                        if constexpr (kFilterDen) {
+                            unpack4u(t32(&F.c[lp][4 + lr][pb8 + 4]), v);
+                            unpack4u(wc.x, v + 4); unpack4u(wc.y, v + 8);
+                            filter_line_d<12>(v, x > 0, inner, level, ilevel, hlevel);
+                            t32(&F.c[lp][4 + lr][pb8 + 4]) = pack4u(v);
+                            wc = make_uint2(pack4u(v + 4), pack4u(v + 8));
+                        } else {
+                            unpack4f(t32(&F.c[lp][4 + lr][pb8 + 4]), v);
+                            unpack4f(wc.x, v + 4); unpack4f(wc.y, v + 8);
+                            filter_line_f<12>(v, x > 0, inner, level_f, ilevel_f, hlevel_f);
+                            t32(&F.c[lp][4 + lr][pb8 + 4]) = pack4f(v);
+                            wc = make_uint2(pack4f(v + 4), pack4f(v + 8));
+                        }
                     }
                 } else if (ftype != 0 && do_filter) {
                     {
@@ -411,16 +428,18 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
                     {
                         uint32_t v[20];
 #pragma unroll
-                        for (int k = 0; k < 20; ++k) v[k] = uint32_t(F.y[k][cb + l]) | kFBias;
-                        filter_line_f<20>(v, y > 0, inner, level_f, ilevel_f, hlevel_f);
+                        for (int k = 0; k < 20; ++k) v[k] = uint32_t(F.y[k][cb + l]) | (kFilterDen ? 0u : kFBias);
+                        if constexpr (kFilterDen) filter_line_d<20>(v, y > 0, inner, level, ilevel, hlevel);
+                        else filter_line_f<20>(v, y > 0, inner, level_f, ilevel_f, hlevel_f);
 #pragma unroll
                         for (int k = 1; k < 19; ++k) F.y[k][cb + l] = uint8_t(v[k]);
                     }
                     {
                         uint32_t v[12];
 #pragma unroll
-                        for (int k = 0; k < 12; ++k) v[k] = uint32_t(F.c[lp][k][cb8 + lr]) | kFBias;
-                        filter_line_f<12>(v, y > 0, inner, level_f, ilevel_f, hlevel_f);
+                        for (int k = 0; k < 12; ++k) v[k] = uint32_t(F.c[lp][k][cb8 + lr]) | (kFilterDen ? 0u : kFBias);
+                        if constexpr (kFilterDen) filter_line_d<12>(v, y > 0, inner, level, ilevel, hlevel);
+                        else filter_line_f<12>(v, y > 0, inner, level_f, ilevel_f, hlevel_f);
 #pragma unroll
                         for (int k = 1; k < 11; ++k) F.c[lp][k][cb8 + lr] = uint8_t(v[k]);
                     }

@@ -84,6 +84,15 @@ __device__ __forceinline__ uint32_t convert_px_opaque(uint32_t ypair, const Chro
     }
     return clip_pack_seq(as_s2(lo), as_s2(hi));
 }
+// The tie correction applied afterwards (taken when some lane of the wavefront holds the tie pair): one off the green byte of a
+// pixel whose chroma sample is the tie pair and whose luma value lies in 111 .. 146.  Green is Y - 18 there (93 .. 128 before
+// the correction), so the byte can simply be decremented: no clamp is in reach.
+__device__ __forceinline__ void tie_patch_row4(uint4& o, uint32_t y4, bool tie0, bool tie1) {
+    o.x -= (tie0 && (y4 & 0xffu) - 111u <= 35u) ? 0x00010000u : 0u;
+    o.y -= (tie0 && ((y4 >> 8) & 0xffu) - 111u <= 35u) ? 0x00010000u : 0u;
+    o.z -= (tie1 && ((y4 >> 16) & 0xffu) - 111u <= 35u) ? 0x00010000u : 0u;
+    o.w -= (tie1 && (y4 >> 24) - 111u <= 35u) ? 0x00010000u : 0u;
+}
 __device__ __forceinline__ uint4 convert_row4_opaque(uint32_t y4, const ChromaPairs& c0, const ChromaPairs& c1) {
     const uint32_t y02 = y4 & 0x00ff00ffu, y13 = (y4 >> 8) & 0x00ff00ffu;
     return make_uint4(convert_px_opaque<0>(y02, c0), convert_px_opaque<0>(y13, c0), convert_px_opaque<1>(y02, c1), convert_px_opaque<1>(y13, c1));
