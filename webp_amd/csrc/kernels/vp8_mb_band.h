@@ -137,13 +137,34 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
     // Band boundary (group 0 only), per column: the unfiltered bottom row of the band above (lanes 0-7: one dword each of
     // its edge record) and the 4 filtered rows above (luma: lane = (row, 4-column quarter), chroma: lane = (plane, row,
     // half); columns 0..7 of MB x come from S tile x, columns 8..15 from S tile x+1).  col: the MB column to fetch.
+    // (the lane's share of the three addresses is computed once per band and kept in registers: since the fp32 edges the
+    // kernel has ~20 registers to spare under its cap, and re-deriving them cost 25 instructions per step)
+    uint32_t fa_e, fa_y, fa_c;
+    {
+        const int l = int(threadIdx.x) & 15;
+        const int lp = l >> 3, hcr = (l >> 1) & 3, hh = l & 1, qr = l >> 2, qd = l & 3;
+        const uint32_t srow0 = uint32_t(band * kBandRows) * uint32_t(spitch) * uint32_t(kTileBytes);
+        fa_e = etop + uint32_t(kEdgeBytes) + 4u * uint32_t(l);
+        fa_y = srow0 + uint32_t(qd >> 1) * uint32_t(kTileBytes) + uint32_t(16 * (4 + qr) + (qd < 2 ? 8 + 4 * qd : 4 * (qd - 2)));
+        fa_c = srow0 + uint32_t(hh) * uint32_t(kTileBytes) + uint32_t(kTileCb + 64 * lp + 8 * hcr + 4 * (1 - hh));
+    }
+    // tile preparation (prepareYBR): the lane's LDS addresses, likewise
+    uint8_t *py_left, *pc_left, *p_top, *p_rr;
+    {
+        const int ln = int(threadIdx.x) & 63, g = ln >> 4, l = ln & 15;
+        MbGroupLds& G = lds.grp[g];
+        ReconTile& T = G.rt;
+        py_left = &T.y[l][3];                                                  // + 16: column 19, the previous MB's last
+        pc_left = &T.c[min(l, 8)][3];                                          // + 8 / + 24: columns 11 / 27; + 16: column 19
+        p_top = l < 4 ? &T.y[0][4 + 4 * l] : l == 4 ? &T.y[0][20] : l < 8 ? &T.c[0][4 + 4 * (l - 6)]
+              : l < 10 ? &T.c[0][20 + 4 * (l - 8)] : &T.y[4 * (l - 9)][20];  // where this lane's dword of the row above goes
+        p_rr = reinterpret_cast<uint8_t*>(&G.rring(0, l < 4 ? l : (l >= 6 && l <= 9) ? l - 2 : 3));      // + 96 per ring slot
+    }
     auto fetch_above = [&](int col, int ln, bool edge_too) {
         const int l = ln & 15;
-        const int lp = l >> 3, hcr = (l >> 1) & 3, hh = l & 1, qr = l >> 2, qd = l & 3;
-        const uint32_t srow = uint32_t(band * kBandRows) * uint32_t(spitch) * uint32_t(kTileBytes) + uint32_t(col) * uint32_t(kTileBytes);
-        if (l < 8 && edge_too) top_n = *reinterpret_cast<const uint32_t*>(E + size_t(etop + uint32_t(col + 1) * uint32_t(kEdgeBytes) + 4u * uint32_t(l)));
-        nx_ty = *reinterpret_cast<const uint32_t*>(S + size_t(srow + uint32_t(qd >> 1) * uint32_t(kTileBytes) + uint32_t(16 * (4 + qr) + (qd < 2 ? 8 + 4 * qd : 4 * (qd - 2)))));
-        nx_tc = *reinterpret_cast<const uint32_t*>(S + size_t(srow + uint32_t(hh) * uint32_t(kTileBytes) + uint32_t(kTileCb + 64 * lp + 8 * hcr + 4 * (1 - hh))));
+        if (l < 8 && edge_too) top_n = *reinterpret_cast<const uint32_t*>(E + size_t(fa_e + uint32_t(col) * uint32_t(kEdgeBytes)));
+        nx_ty = *reinterpret_cast<const uint32_t*>(S + size_t(fa_y + uint32_t(col) * uint32_t(kTileBytes)));
+        nx_tc = *reinterpret_cast<const uint32_t*>(S + size_t(fa_c + uint32_t(col) * uint32_t(kTileBytes)));
     };
     {
         const int ln = opaque_lane();
@@ -230,10 +251,9 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
             if (act) {
                 // ---- prepareYBR (Vp8Decoder.hx:541-577) ----
                 {
-                    const int lc = min(l, 8);
-                    uint32_t va = T.y[l][19], vb = T.y[16][19], vc1 = T.c[lc][11], vc2 = T.c[lc][27];     // last column of the previous MB
+                    uint32_t va = py_left[16], vb = T.y[16][19], vc1 = pc_left[8], vc2 = pc_left[24];     // last column of the previous MB: T.y[l][19], T.c[min(l, 8)][11 / 27]
                     const bool tr_job = l == 4 || (l >= 10 && l <= 12);
-                    uint32_t rv = G.rring(x & 3, l < 4 ? l : (l >= 6 && l <= 9) ? l - 2 : 3);
+                    uint32_t rv = *reinterpret_cast<uint32_t*>(p_rr + 96 * (x & 3));                       // G.rring(x & 3, l < 4 ? l : 6 <= l <= 9 ? l - 2 : 3)
                     const uint32_t nxt = G.rring((x + 1) & 3, 0);
                     if (tr_job) rv = x == mbw - 1 ? splat4(int(rv >> 24)) : nxt;
                     if (x == 0) { va = 0x81; vb = 0x81; vc1 = 0x81; vc2 = 0x81; }
@@ -241,12 +261,10 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
                         rv = 0x7f7f7f7fu;
                         if (l == 0) { va = 0x7f; vc1 = 0x7f; vc2 = 0x7f; }
                     }
-                    T.y[l][3] = uint8_t(va);
+                    py_left[0] = uint8_t(va);                                                               // T.y[l][3]
                     if (l == 0) T.y[16][3] = uint8_t(vb);
-                    if (l < 9) { T.c[l][3] = uint8_t(vc1); T.c[l][19] = uint8_t(vc2); }
-                    uint8_t* dst = l < 4 ? &T.y[0][4 + 4 * l] : l == 4 ? &T.y[0][20] : l < 8 ? &T.c[0][4 + 4 * (l - 6)]
-                                 : l < 10 ? &T.c[0][20 + 4 * (l - 8)] : &T.y[4 * (l - 9)][20];
-                    if (l < 5 || (l >= 6 && l <= 12)) tile32(dst, 0) = rv;
+                    if (l < 9) { pc_left[0] = uint8_t(vc1); pc_left[16] = uint8_t(vc2); }                  // T.c[l][3], T.c[l][19]
+                    if (l < 5 || (l >= 6 && l <= 12)) tile32(p_top, 0) = rv;
                 }
                 __builtin_amdgcn_wave_barrier();
                 // ---- luma, 16x16 ----
