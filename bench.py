@@ -310,6 +310,11 @@ def main():
         alg = {"vp8_mb_kernel": in_bytes + yuv_bytes, "vp8_finish_kernel": alg["vp8_finish_kernel"]}
         times = {"vp8_mb_kernel": t_recon, "vp8_finish_kernel": t_conv}
     dom = max(times, key=times.get)
+    # The two kernels of a pipelined step run beside each other for the whole step and are balanced to end together, so which
+    # of them is a few microseconds longer changes from run to run: within 3 % the persistent kernel (the one bound by
+    # instruction issue, with the lower fraction of the HBM roofline) is the one reported.
+    if args.one_launch and times["vp8_mb_kernel"] >= 0.97 * times[dom]:
+        dom = "vp8_mb_kernel"
     achieved = alg[dom] / (times[dom] * 1e-3) / 1e9                    # bytes per step / time per step = bytes per launch / time per launch
     launches = finish_per_step if dom == "vp8_finish_kernel" else 1.0
     # HBM traffic of that kernel from the PMC counters: measured by a separate rocprofv3 --pmc run of this same command
@@ -317,7 +322,8 @@ def main():
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json" if args.one_launch else "r01_traffic.json")))
-        traffic = int(tj["kernels"][dom]["hbm_bytes"] * args.images / tj["images_per_launch"] / launches)
+        key = next(k for k in tj["kernels"] if dom in k)            # rocprofv3 spells template instances "void vp8_mb_kernel<8>"
+        traffic = int(tj["kernels"][key]["hbm_bytes"] * args.images / tj["images_per_launch"] / launches)
     except Exception:
         pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -69,10 +69,13 @@ void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* _
     // 5.52 / 6.26 ms): the sum of the two is what the SIMDs' issue slots allow, and a step is 6.4 - 7.0 ms against 5.8.
     const int n_here = min(kFinishPerWg, (c_end - c_first + kFinishCols - 1) / kFinishCols);
     if (WP_FINISH_FAST && finish_is_interior(fr, ty, c_first + (n_here - 1) * kFinishCols, shifted, Yp, Up, Vp, Ap, out)) {
-        u32x4 nx = finish_fetch(finish_src(fr, ty, c_first, Rp, Sp, shifted), t);
+        // an interior chunk's 9 source tiles all exist, and the next chunk's start 8 tiles further on: the source is one pointer
+        const u32x4* src = reinterpret_cast<const u32x4*>(finish_src(fr, ty, c_first, Rp, Sp, true).src);
+        FinishBases fb = finish_bases(fr, ty, c_first, Yp, Up, Vp, out);
+        u32x4 nx = {0u, 0u, 0u, 0u};
+        if (t < kFinishTiles * (kTileBytes / 16)) nx = WP_NT_LOAD(src + t);
 #pragma unroll
         for (int i = 0; i < kFinishPerWg; ++i) {
-            const int c0 = c_first + i * kFinishCols;
             if (i >= n_here) break;
             if (i) __syncthreads();                           // the chunk before has been read out of LDS
             int tt = t;
@@ -82,9 +85,11 @@ void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* _
 #endif
             if (tt < kFinishTiles * (kTileBytes / 16)) tiles4[tt] = make_uint4(nx.x, nx.y, nx.z, nx.w);
             __syncthreads();
-            if (i + 1 < n_here) nx = finish_fetch(finish_src(fr, ty, c0 + kFinishCols, Rp, Sp, shifted), tt);
+            src += (kFinishTiles - 1) * (kTileBytes / 16);
+            if (i + 1 < n_here && tt < kFinishTiles * (kTileBytes / 16)) nx = WP_NT_LOAD(src + tt);
             __builtin_amdgcn_sched_barrier(0);
-            finish_emit_interior(fr, ty, c0, tt, tiles4, shifted, Yp, Up, Vp, out);
+            finish_emit_interior(fb, tt, tiles4);
+            fb.next_chunk();
             __builtin_amdgcn_sched_barrier(0);
         }
         return;

@@ -141,15 +141,30 @@ __device__ __forceinline__ bool finish_is_interior(const wp_vp8_frame& fr, int t
            row0 + 16 <= fr.height && c0 + kFinishCols <= fr.width && (fr.width & 3) == 0 &&
            ((reinterpret_cast<uintptr_t>(out) + fr.argb_off) & 15) == 0;
 }
-// A wavefront that holds the chroma pair whose green term needs the Y-dependent tie correction (wp_convert.h) takes the
-// conversion with the correction for the chunk (a wavefront-uniform branch).
-__device__ __forceinline__ void finish_emit_interior(const wp_vp8_frame& fr, int ty, int c0, int t, const uint4* tiles4, bool shifted,
-                                                     uint8_t* Yp, uint8_t* Up, uint8_t* Vp, uint8_t* out) {
+// Everything about an interior chunk that does not depend on the thread, as scalars the workgroup computes once and advances
+// from chunk to chunk (the descriptor lives in memory: read through `fr` inside the chunk loop it was re-loaded, and waited
+// for, four times per chunk).
+struct FinishBases {
+    uint8_t *y, *argb, *u, *v;          // first byte of the chunk's first row in each output
+    uint32_t ystride, cstride, width;
+    __device__ __forceinline__ void next_chunk() { y += kFinishCols; argb += 4 * kFinishCols; u += kFinishCols / 2; v += kFinishCols / 2; }
+};
+__device__ __forceinline__ FinishBases finish_bases(const wp_vp8_frame& fr, int ty, int c0, uint8_t* Yp, uint8_t* Up, uint8_t* Vp, uint8_t* out) {
+    FinishBases b;
+    b.ystride = 16u * uint32_t(fr.mbw); b.cstride = 8u * uint32_t(fr.mbw); b.width = uint32_t(fr.width);
+    const uint32_t row0 = uint32_t(16 * ty - kFiltShift);                          // first luma row of the chunk (interior: >= 0)
+    b.y = Yp + fr.y_off + size_t(row0 * b.ystride + uint32_t(c0));
+    b.argb = out + fr.argb_off + 4u * size_t(row0 * b.width + uint32_t(c0));
+    const size_t coff = size_t((row0 >> 1) * b.cstride + (uint32_t(c0) >> 1));
+    b.u = Up + fr.u_off + coff; b.v = Vp + fr.v_off + coff;
+    return b;
+}
+// A wavefront that holds the chroma pair whose green term needs the Y-dependent tie correction (wp_convert.h) patches the
+// pixels concerned afterwards (a wavefront-uniform branch).  Shifted (S) tiles only.
+__device__ __forceinline__ void finish_emit_interior(const FinishBases& fb, int t, const uint4* tiles4) {
     const uint32_t* tiles32 = reinterpret_cast<const uint32_t*>(tiles4);
     const uint16_t* tiles16 = reinterpret_cast<const uint16_t*>(tiles4);
-    const uint32_t shift = shifted ? uint32_t(kFiltShift) : 0u;
-    const uint32_t ystride = 16u * uint32_t(fr.mbw), cstride = 8u * uint32_t(fr.mbw), width = uint32_t(fr.width);
-    const uint32_t row0 = uint32_t(16 * ty) - shift;                               // scalar: first luma row of the chunk
+    constexpr uint32_t shift = uint32_t(kFiltShift);
     {
         const uint32_t q = uint32_t(t) & 31u, rp = uint32_t(t) >> 5;
         const uint32_t cs = 4u * q + shift;                                         // column inside the chunk's tiles
@@ -165,17 +180,15 @@ __device__ __forceinline__ void finish_emit_interior(const wp_vp8_frame& fr, int
         const bool any_tie = __builtin_amdgcn_ballot_w64(t0.tie || t1.tie) != 0;
         const ChromaPairs cp0 = chroma_pairs(t0), cp1 = chroma_pairs(t1);
         const uint32_t ya = tiles32[lbase], yb = tiles32[lbase + 4];
-        uint8_t* const Yrow = Yp + fr.y_off + size_t(row0 * ystride + uint32_t(c0));
-        const uint32_t yo = __umul24(2u * rp, ystride) + 4u * q;
-        WP_PLANE_STORE(reinterpret_cast<uint32_t*>(Yrow + yo), ya);
-        WP_PLANE_STORE(reinterpret_cast<uint32_t*>(Yrow + ystride + yo), yb);
-        uint8_t* const Arow = out + fr.argb_off + 4u * size_t(row0 * width + uint32_t(c0));
-        const uint32_t po = 4u * (__umul24(2u * rp, width) + 4u * q);
+        const uint32_t yo = __umul24(2u * rp, fb.ystride) + 4u * q;
+        WP_PLANE_STORE(reinterpret_cast<uint32_t*>(fb.y + yo), ya);
+        WP_PLANE_STORE(reinterpret_cast<uint32_t*>(fb.y + fb.ystride + yo), yb);
+        const uint32_t po = 4u * (__umul24(2u * rp, fb.width) + 4u * q);
         __builtin_amdgcn_sched_barrier(0);      // one row at a time: interleaved, the two conversions need 38 registers (budget: 32)
         uint4 o0 = convert_row4_opaque(ya, cp0, cp1);
         if (any_tie) tie_patch_row4(o0, ya, t0.tie, t1.tie);
         const u32x4 w0 = {o0.x, o0.y, o0.z, o0.w};
-        WP_ARGB_STORE(reinterpret_cast<u32x4*>(Arow + po), w0);
+        WP_ARGB_STORE(reinterpret_cast<u32x4*>(fb.argb + po), w0);
 #if WP_FINISH_PRIO_LO != WP_FINISH_PRIO && WP_FINISH_LO_AT == 1
         __builtin_amdgcn_s_setprio(WP_FINISH_PRIO_LO);       // the second half of a chunk at the lower priority (see vp8_finish.hip)
 #endif
@@ -183,7 +196,7 @@ __device__ __forceinline__ void finish_emit_interior(const wp_vp8_frame& fr, int
         uint4 o1 = convert_row4_opaque(yb, cp0, cp1);
         if (any_tie) tie_patch_row4(o1, yb, t0.tie, t1.tie);
         const u32x4 w1 = {o1.x, o1.y, o1.z, o1.w};
-        WP_ARGB_STORE(reinterpret_cast<u32x4*>(Arow + 4u * width + po), w1);
+        WP_ARGB_STORE(reinterpret_cast<u32x4*>(fb.argb + 4u * fb.width + po), w1);
 #if WP_FINISH_PRIO_LO != WP_FINISH_PRIO && WP_FINISH_LO_AT == 2
         __builtin_amdgcn_s_setprio(WP_FINISH_PRIO_LO);
 #endif
@@ -193,8 +206,8 @@ __device__ __forceinline__ void finish_emit_interior(const wp_vp8_frame& fr, int
         const uint32_t plane = uint32_t(__builtin_amdgcn_readfirstlane(t)) >> 7;      // wavefronts 0, 1: Cb; 2, 3: Cr
         const uint32_t row = (uint32_t(t) >> 4) & 7u, dw = uint32_t(t) & 15u;
         const uint32_t cs = 4u * dw + (shift >> 1);
-        uint8_t* const P = (plane ? Vp + fr.v_off : Up + fr.u_off) + size_t(((row0 >> 1)) * cstride + (uint32_t(c0) >> 1));
-        WP_PLANE_STORE(reinterpret_cast<uint32_t*>(P + (__umul24(row, cstride) + 4u * dw)),
+        uint8_t* const P = plane ? fb.v : fb.u;
+        WP_PLANE_STORE(reinterpret_cast<uint32_t*>(P + (__umul24(row, fb.cstride) + 4u * dw)),
                     tiles32[(cs >> 3) * uint32_t(kTileBytes / 4) + uint32_t(kTileCb / 4) + 16u * plane + 2u * row + ((cs >> 2) & 1u)]);
     }
 }

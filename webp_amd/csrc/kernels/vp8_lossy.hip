@@ -20,15 +20,16 @@ namespace wpk {
 constexpr int kMbWaves = WP_MB_WAVES;
 constexpr int kMbWGsPerCU = WP_MB_WGS_PER_CU;
 
-// Register budget: 112 VGPRs.  Two workgroups of this kernel leave a SIMD 512 - 4 x 112 = 64 registers per lane: two waves of
-// the finishing pass (32 each), which is what a pipelined step runs beside it.  At 113..128 only ONE fits and the step gets
-// 8 % longer although this kernel alone gets faster -- and the register allocator, which only sees that LDS caps the kernel
-// at 4 waves per SIMD anyway, uses up to 128 freely.  (The attribute counts in units of two registers on gfx90a and later.)
-// A third finishing wave per SIMD (this kernel at 104 registers, measured with a timing-only build that needs no spills
-// there) makes the step LONGER, 6.35 -> 6.98 ms: the pass then takes more issue slots from this kernel, which is the
-// step's critical path.
+// Register budget: 104 VGPRs.  Two workgroups of this kernel then leave a SIMD 512 - 4 x 104 = 96 registers per lane: three
+// waves of the finishing pass (32 each; the LDS left beside this kernel holds three of its workgroups per CU), which is what
+// a pipelined step runs beside it -- its issue priorities are tuned for that (vp8_finish.hip).  The register allocator only
+// sees that LDS caps this kernel at 4 waves per SIMD anyway and would use up to 128 freely: at 105..112 two finishing waves
+// fit, at 113..128 one, and the step gets longer although this kernel alone gets faster (round 3, integer edges, 111 -> 115
+// registers: 6.38 -> 6.94 ms).  (The attribute counts in units of two registers on gfx90a and later.)
+// History: with the integer loop-filter edges the kernel needed 112 and spilt below; the fp32 edges on denormals need 92, and
+// the 12 registers between are spent on per-lane addresses that are no longer re-derived in every step (vp8_mb_band.h).
 #ifndef WP_MB_NUM_VGPR
-#define WP_MB_NUM_VGPR 56
+#define WP_MB_NUM_VGPR 52
 #endif
 // W wavefronts per workgroup pipeline the bands of one frame: 8, two workgroups per CU.  Four-wave workgroups (four per CU,
 // WP_MB_FORCE_WAVES=4) were tried for batches with fewer frames than workgroup slots, where frames would spread more evenly
