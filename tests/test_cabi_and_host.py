@@ -328,3 +328,14 @@ def test_anmf_header_larger_than_the_vp8_stream_does_not_fail_the_batch():
     assert pf.frames[0].width == 4000
     b = LossyBatch(pf.frames)
     assert (b.desc[0].width, b.desc[0].height) == (1280, 720) and (b.desc[1].width, b.desc[1].height) == (1280, 720)
+
+
+def test_build_pins_the_floating_point_flags_the_kernels_rely_on():
+    """The loop filter computes its edge masks on fp32 denormals and the colour conversion must not be contracted: both are
+    build flags (webp_amd/csrc/Makefile).  That the built kernels behave accordingly is what the GPU parity tests show (a
+    build that flushes denormals filters no edge at all)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mk = open(os.path.join(root, "webp_amd", "csrc", "Makefile")).read()
+    flags = [l for l in mk.split("\n") if l.startswith("HIPFLAGS") or l.startswith("CXXFLAGS")]
+    assert any("-fno-gpu-flush-denormals-to-zero" in l for l in flags) and any("-ffp-contract=off" in l for l in flags)
