@@ -152,7 +152,7 @@ def main():
                     "0 = every rank decodes --images images (weak scaling, the default)")
     ap.add_argument("--serial", action="store_true", help="one stream per step, no overlap between steps (kernel times as when each runs alone)")
     ap.add_argument("--split", type=float, default=0.6, help="share of a step's frames whose finishing pass runs beside the next reconstruction (the rest: beside the next loop filter)")
-    ap.add_argument("--finish-delay-us", type=float, default=15.0, help="how long a finishing pass is held back so that the persistent kernel of its phase is dispatched first")
+    ap.add_argument("--finish-delay-us", type=float, default=None, help="least time a finishing pass is held back behind the launch of the persistent kernel beside it (the library pipeline waits for that kernel's workgroups to be placed anyway; default 0; 40 for --py-pipeline, which only has the time)")
     ap.add_argument("--two-phase", action="store_true", help="round-1 schedule: reconstruction and loop filter as two kernels (R tiles through HBM), the finishing pass of the step before split over both")
     ap.add_argument("--py-pipeline", action="store_true", help="pipeline the steps with webp_amd.device.LossyPipeline (torch streams, torch.cuda._sleep as hold-off) instead of the library's own wp_vp8_pipeline_* (the default)")
     ap.add_argument("--workspaces", type=int, default=2, help="tile workspaces the pipelined steps rotate through")
@@ -215,7 +215,7 @@ def main():
     elif native:                                     # the C ABI's pipeline: its own streams, workspaces (allocated here) and hold-off
         pipe = NativePipeline(device, work_bytes=db.work_bytes, workspaces=args.workspaces, timing=True, hold_us=args.finish_delay_us)
     else:
-        pipe = LossyPipeline(device, split=args.split, finish_delay_us=args.finish_delay_us, one_launch=args.one_launch, workspaces=args.workspaces)
+        pipe = LossyPipeline(device, split=args.split, finish_delay_us=40.0 if args.finish_delay_us is None else args.finish_delay_us, one_launch=args.one_launch, workspaces=args.workspaces)
         for k in range(args.workspaces):
             db.workspace(k)                          # allocated here, not inside the timed region
 

@@ -299,7 +299,7 @@ int wp_vp8_pipeline_drain(wp_vp8_pipeline* p);
 /* Accumulated duration (ms) of the reconstruction + loop filter launches and of the finishing launches of the steps that
  * have completed, each measured with HIP events on the stream the kernel runs on, and their number. */
 int wp_vp8_pipeline_stats(wp_vp8_pipeline* p, double* ms_recon_filter, double* ms_finish, long* steps, int reset);
-int wp_vp8_pipeline_set_hold_us(wp_vp8_pipeline* p, int us);      /* tuning: the hold-off, default 15 */
+int wp_vp8_pipeline_set_hold_us(wp_vp8_pipeline* p, int us);      /* tuning: least time (us) the finishing pass is held back, on top of the wait for the persistent kernel to be placed; default 0 */
 int wp_vp8_pipeline_destroy(wp_vp8_pipeline* p);
 
 /* VP8L inverse transform chain + RGBA->ARGB swizzle.  Replaces Transform.hx inversePredictor /

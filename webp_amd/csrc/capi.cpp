@@ -24,7 +24,11 @@ int wpk_vp8l_side_init(int dev);
 void wpk_vp8l_side_shutdown(void);
 void wpk_resolve_force_ring(int px);
 int wpk_launch_vp8_recon_filter(int n, int cus, const wp_vp8_frame* d_frames, int use_turns, const void* d_mb, const int16_t* d_coeff,
-                                const uint32_t* d_filt, uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream);
+                                const uint32_t* d_filt, uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream,
+                                uint32_t* d_started, uint32_t* workgroups);
+int wpk_vp8_recon_filter_counted(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint32_t* d_mb, const uint32_t* d_filt,
+                                 const int16_t* d_coeff, void* d_work, size_t work_bytes, void* stream, uint32_t* d_started,
+                                 uint32_t* workgroups);
 int wpk_launch_vp8_finish(int n, int chunks, int tile_rows, int alone, const wp_vp8_frame* d_frames, const uint8_t* d_rtiles,
                           const uint8_t* d_stiles, int force_unshifted, uint8_t* d_y, uint8_t* d_u, uint8_t* d_v,
                           const uint8_t* d_alpha, uint8_t* d_argb, hipStream_t stream);
@@ -357,6 +361,14 @@ int wp_vp8_loopfilter_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd,
 
 int wp_vp8_recon_filter_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint32_t* d_mb, const uint32_t* d_filt,
                             const int16_t* d_coeff, void* d_work, size_t work_bytes, void* stream) {
+    return wpk_vp8_recon_filter_counted(n, fh, fd, d_mb, d_filt, d_coeff, d_work, work_bytes, stream, nullptr, nullptr);
+}
+
+// The same with a device counter that every workgroup of the launch(es) bumps once as it starts, and the number of workgroups
+// launched (added to *workgroups): wp_vp8_pipeline_* holds its finishing stream back until the two are equal.  Internal.
+int wpk_vp8_recon_filter_counted(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint32_t* d_mb, const uint32_t* d_filt,
+                                 const int16_t* d_coeff, void* d_work, size_t work_bytes, void* stream, uint32_t* d_started,
+                                 uint32_t* workgroups) {
     int rc = ensure_init(); if (rc) return rc;
     rc = check_vp8_frames(n, fh); if (rc) return rc;
     if (n == 0) return WP_OK;
@@ -368,7 +380,7 @@ int wp_vp8_recon_filter_dev(int n, const wp_vp8_frame* fh, const wp_vp8_frame* f
     for (int first = 0; first < n; first += per) {
         const int cnt = std::min(per, n - first);
         const int e = wpk_launch_vp8_recon_filter(cnt, g_cus.load(std::memory_order_relaxed), fd + first, turns_valid(cnt, fh + first) ? 1 : 0, d_mb, d_coeff,
-                                                  d_filt, work, work + w.r_bytes, hipStream_t(stream));
+                                                  d_filt, work, work + w.r_bytes, hipStream_t(stream), d_started, workgroups);
         if (e) return hip_fail(hipError_t(e), "vp8_mb launch");
     }
     return WP_OK;

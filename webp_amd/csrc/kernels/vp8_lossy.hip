@@ -38,10 +38,13 @@ constexpr int kMbWGsPerCU = WP_MB_WGS_PER_CU;
 template <int W>
 __global__ __attribute__((amdgpu_num_vgpr(WP_MB_NUM_VGPR))) __launch_bounds__(W * kWave, (kMbWaves * kMbWGsPerCU + 3) / 4)
 void vp8_mb_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, int use_turns, const uint4* __restrict__ mb,
-                   const int16_t* __restrict__ coeff, const uint32_t* __restrict__ filt, uint8_t* Ep, uint8_t* Sp) {
+                   const int16_t* __restrict__ coeff, const uint32_t* __restrict__ filt, uint8_t* Ep, uint8_t* Sp, uint32_t* started) {
     __shared__ MbWaveLds lds_all[W];
     __shared__ uint32_t progress[W];
     const int wave = threadIdx.x >> 6;
+    // "this workgroup has been placed": what a pipelining caller's other stream waits for before it lets a streaming kernel
+    // onto the CUs (pipeline.cpp; a count of workgroups, not a time)
+    if (started != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x < W) progress[threadIdx.x] = 0;
     __syncthreads();
 
@@ -62,17 +65,20 @@ void vp8_mb_kernel(int n_frames, const wp_vp8_frame* __restrict__ frames, int us
 }  // namespace wpk
 
 extern "C" int wpk_launch_vp8_recon_filter(int n, int cus, const wp_vp8_frame* d_frames, int use_turns, const void* d_mb, const int16_t* d_coeff,
-                                           const uint32_t* d_filt, uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream) {
+                                           const uint32_t* d_filt, uint8_t* d_rtiles, uint8_t* d_stiles, hipStream_t stream,
+                                           uint32_t* d_started, uint32_t* workgroups) {
     static const int force_w = std::getenv("WP_MB_FORCE_WAVES") ? std::atoi(std::getenv("WP_MB_FORCE_WAVES")) : 0;      // tuning switch
     const bool small = force_w == 4;
     if (small) {        // four-wave workgroups, four per CU: measured on cfg 4 (300 x 720p, fewer frames than workgroup slots), not the default
         const int slots = cus * wpk::kMbWGsPerCU * 2;
+        if (workgroups) *workgroups += uint32_t(n < slots ? n : slots);
         hipLaunchKernelGGL(wpk::vp8_mb_kernel<wpk::kMbWaves / 2>, dim3(n < slots ? n : slots), dim3(wpk::kMbWaves / 2 * wpk::kWave), 0, stream,
-                           n, d_frames, use_turns, reinterpret_cast<const uint4*>(d_mb), d_coeff, d_filt, d_rtiles, d_stiles);
+                           n, d_frames, use_turns, reinterpret_cast<const uint4*>(d_mb), d_coeff, d_filt, d_rtiles, d_stiles, d_started);
     } else {
         const int grid = n < cus * wpk::kMbWGsPerCU ? n : cus * wpk::kMbWGsPerCU;
+        if (workgroups) *workgroups += uint32_t(grid);
         hipLaunchKernelGGL(wpk::vp8_mb_kernel<wpk::kMbWaves>, dim3(grid), dim3(wpk::kMbWaves * wpk::kWave), 0, stream,
-                           n, d_frames, use_turns, reinterpret_cast<const uint4*>(d_mb), d_coeff, d_filt, d_rtiles, d_stiles);
+                           n, d_frames, use_turns, reinterpret_cast<const uint4*>(d_mb), d_coeff, d_filt, d_rtiles, d_stiles, d_started);
     }
     return int(hipGetLastError());
 }

@@ -1020,6 +1020,11 @@ extern "C" int wpk_launch_delay(int us, hipStream_t stream) {
     hipLaunchKernelGGL(wpk::delay_kernel, dim3(1), dim3(64), 0, stream, us);
     return int(hipGetLastError());
 }
+// ... and its progress-driven form: until `target` workgroups of the persistent kernel have announced themselves
+extern "C" int wpk_launch_hold_until(const uint32_t* d_counter, uint32_t target, int min_us, int max_us, hipStream_t stream) {
+    hipLaunchKernelGGL(wpk::hold_until_kernel, dim3(1), dim3(64), 0, stream, d_counter, target, min_us, max_us);
+    return int(hipGetLastError());
+}
 // wp_shutdown: the side streams and their events go; wp_init creates them again on demand
 extern "C" void wpk_vp8l_side_shutdown(void) {
     std::lock_guard<std::mutex> lock(g_side_mutex);

@@ -6,10 +6,13 @@
 //
 // The finishing pass is bound by memory bandwidth, the one-kernel reconstruction + loop filter by instruction issue; side by
 // side they fill each other's gaps.  Batches rotate through the pipeline's own tile workspaces, so the kernel
-// of batch k+1 never touches the tiles the finishing pass of batch k still reads.  The finishing launch is held back a few
-// tens of microseconds behind the event it waits for (a one-wavefront spin kernel): both kernels become runnable at the same
-// moment, and if the streaming one is dispatched first the persistent kernel's workgroups are placed piecemeal as it drains
-// and the step takes a third longer.  No counterpart in the reference (one image per call, no device).
+// of batch k+1 never touches the tiles the finishing pass of batch k still reads.  The finishing launch is held back until
+// every workgroup of the persistent kernel beside it has been placed: both kernels become runnable at the same moment, and if
+// the streaming one is dispatched first the persistent kernel's workgroups are placed piecemeal as it drains and the step
+// takes a third longer.  Held back by PROGRESS: the persistent kernel's workgroups count themselves in a device word as they
+// start, and a one-wavefront kernel on the finish stream polls it (with a time-out, so that a launch that failed cannot leave
+// a spinning wavefront behind); rounds 1 and 2 waited a fixed 40 us, a constant of this GPU.  wp_vp8_pipeline_set_hold_us adds
+// a minimum time on top (default 0).  No counterpart in the reference (one image per call, no device).
 //
 // Everything here is host code over the library's public *_dev entry points.
 #include <hip/hip_runtime.h>
@@ -21,13 +24,18 @@
 
 namespace wp { void set_error(const std::string& msg); }
 extern "C" int wpk_launch_delay(int us, hipStream_t stream);
+extern "C" int wpk_launch_hold_until(const uint32_t* d_counter, uint32_t target, int min_us, int max_us, hipStream_t stream);
+extern "C" int wpk_vp8_recon_filter_counted(int n, const wp_vp8_frame* fh, const wp_vp8_frame* fd, const uint32_t* d_mb, const uint32_t* d_filt,
+                                            const int16_t* d_coeff, void* d_work, size_t work_bytes, void* stream, uint32_t* d_started,
+                                            uint32_t* workgroups);
 
 struct wp_vp8_pipeline {
     int device = 0;
     hipStream_t s_main = nullptr, s_fin = nullptr;
     size_t ws_bytes = 0;
     std::vector<void*> ws;
-    int hold_us = 15;      // the finishing pass starts this long after the persistent kernel of the next batch (placement); 10 .. 40 us measure alike, 0 is 30 % slower
+    int hold_us = 0;       // least time the finishing pass is held back behind the launch of the next batch's persistent kernel, on top of the wait for its workgroups
+    uint32_t* d_started = nullptr;                 // kCounters device words, one per step in flight (step k uses k % kCounters)
     int max_in_flight = 3;
     bool timing = false;
     uint64_t k = 0;
@@ -39,6 +47,8 @@ struct wp_vp8_pipeline {
         const uint8_t* alpha = nullptr;
         hipEvent_t alpha_ready = nullptr;             // caller's event: the alpha slab is complete (the finishing pass waits for it)
         hipEvent_t mb0 = nullptr, mb1 = nullptr;      // around the reconstruction + loop filter kernel (main stream)
+        uint32_t* started = nullptr;                  // this step's counter of placed workgroups ...
+        uint32_t workgroups = 0;                      // ... and what it reaches
         hipEvent_t fin0 = nullptr, fin1 = nullptr;    // around the finishing pass (finish stream); fin1 = the step's outputs are complete
     };
     Step pending;                  // its finishing pass has not been enqueued yet
@@ -77,13 +87,19 @@ void retire_front(wp_vp8_pipeline* p) {
     p->queued.pop_front();
 }
 
-// enqueue the finishing pass of the pending step on the finish stream
-int enqueue_finish(wp_vp8_pipeline* p, bool hold) {
+constexpr int kCounters = 8;                // > max_in_flight + 2: a counter is long out of use when its turn comes again
+constexpr int kHoldTimeoutUs = 2000;        // the poll gives up after this long whatever the counter says
+
+// enqueue the finishing pass of the pending step on the finish stream; `beside`: the step whose persistent kernel has just
+// been launched and runs beside it (null: nothing does)
+int enqueue_finish(wp_vp8_pipeline* p, const wp_vp8_pipeline::Step* beside) {
     wp_vp8_pipeline::Step& s = p->pending;
     HIP_TRY(hipStreamWaitEvent(p->s_fin, s.mb1, 0));
     if (s.alpha_ready) HIP_TRY(hipStreamWaitEvent(p->s_fin, s.alpha_ready, 0));
-    if (hold && p->hold_us > 0) {
-        const int e = wpk_launch_delay(p->hold_us, p->s_fin);
+    if (beside) {
+        // mb0 of that step was recorded after its counter was cleared and directly before its launch: polling starts then
+        HIP_TRY(hipStreamWaitEvent(p->s_fin, beside->mb0, 0));
+        const int e = wpk_launch_hold_until(beside->started, beside->workgroups, p->hold_us, kHoldTimeoutUs + p->hold_us, p->s_fin);
         if (e) return hip_fail(hipError_t(e), "hold-off launch");
     }
     int rc = new_event(p, &s.fin0); if (rc) return rc;
@@ -133,6 +149,7 @@ int wp_vp8_pipeline_create(int n_workspaces, size_t work_bytes, int flags, wp_vp
         const hipError_t e = hipMalloc(&w, work_bytes ? work_bytes : 256);
         if (e != hipSuccess) { w = nullptr; return bail(hip_fail(e, "hipMalloc (pipeline workspace)")); }
     }
+    if (hipMalloc(reinterpret_cast<void**>(&p->d_started), 256 * kCounters) != hipSuccess) { p->d_started = nullptr; return bail(fail(WP_ERR_HIP, "hipMalloc (pipeline counters)")); }
     *out = p;
     return WP_OK;
 }
@@ -172,13 +189,15 @@ int wp_vp8_pipeline_submit(wp_vp8_pipeline* p, int n, const wp_vp8_frame* fh, co
     if (inputs_ready) HIP_TRY(hipStreamWaitEvent(p->s_main, hipEvent_t(inputs_ready), 0));
     rc = new_event(p, &s.mb0); if (rc) return rc;
     rc = new_event(p, &s.mb1); if (rc) { free_step_events(s); return rc; }
+    s.started = p->d_started + 64 * (p->k % kCounters);                         // (256 bytes apart: a line of its own)
+    HIP_TRY(hipMemsetAsync(s.started, 0, sizeof(uint32_t), p->s_main));
     HIP_TRY(hipEventRecord(s.mb0, p->s_main));
-    rc = wp_vp8_recon_filter_dev(n, s.fh.data(), fd, d_mb, d_filt, d_coeff, s.work, p->ws_bytes, p->s_main);
+    rc = wpk_vp8_recon_filter_counted(n, s.fh.data(), fd, d_mb, d_filt, d_coeff, s.work, p->ws_bytes, p->s_main, s.started, &s.workgroups);
     if (rc) { free_step_events(s); return rc; }
     HIP_TRY(hipEventRecord(s.mb1, p->s_main));
     p->k += 1;
     // the finishing pass of the step before goes out now, beside the kernel just launched
-    if (p->has_pending) { rc = enqueue_finish(p, true); if (rc) { free_step_events(s); return rc; } }
+    if (p->has_pending) { rc = enqueue_finish(p, &s); if (rc) { free_step_events(s); return rc; } }
     p->pending = std::move(s);
     p->has_pending = true;
     return WP_OK;
@@ -187,7 +206,7 @@ int wp_vp8_pipeline_submit(wp_vp8_pipeline* p, int n, const wp_vp8_frame* fh, co
 int wp_vp8_pipeline_flush(wp_vp8_pipeline* p, void* stream) {
     if (!p) return fail(WP_ERR_INVALID, "null pipeline");
     DeviceGuard g; int rc = g.enter(p->device); if (rc) return rc;
-    if (p->has_pending) { rc = enqueue_finish(p, false); if (rc) return rc; }     // nothing left to overlap it with: no hold-off
+    if (p->has_pending) { rc = enqueue_finish(p, nullptr); if (rc) return rc; }     // nothing left to overlap it with: no hold-off
     if (!p->queued.empty()) HIP_TRY(hipStreamWaitEvent(hipStream_t(stream), p->queued.back().fin1, 0));
     return WP_OK;
 }
@@ -195,7 +214,7 @@ int wp_vp8_pipeline_flush(wp_vp8_pipeline* p, void* stream) {
 int wp_vp8_pipeline_drain(wp_vp8_pipeline* p) {
     if (!p) return fail(WP_ERR_INVALID, "null pipeline");
     DeviceGuard g; int rc = g.enter(p->device); if (rc) return rc;
-    if (p->has_pending) { rc = enqueue_finish(p, false); if (rc) return rc; }
+    if (p->has_pending) { rc = enqueue_finish(p, nullptr); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(p->s_main));
     HIP_TRY(hipStreamSynchronize(p->s_fin));
     while (!p->queued.empty()) retire_front(p);
@@ -226,6 +245,7 @@ int wp_vp8_pipeline_destroy(wp_vp8_pipeline* p) {
     if (p->has_pending) free_step_events(p->pending);
     for (auto& s : p->queued) free_step_events(s);
     for (void* w : p->ws) if (w) (void)hipFree(w);
+    if (p->d_started) (void)hipFree(p->d_started);
     if (p->s_main) (void)hipStreamDestroy(p->s_main);
     if (p->s_fin) (void)hipStreamDestroy(p->s_fin);
     delete p;
