@@ -82,3 +82,42 @@ def test_interior_and_general_paths(kind, filter_type):
         bad = np.flatnonzero(got != exp["argb"])
         assert bad.size == 0, "frame %d (%dx%d): %d ARGB bytes differ, first at pixel (%d, %d) channel %d: got %d want %d" % (
             i, d.width, d.height, bad.size, (bad[0] // 4) % d.width, (bad[0] // 4) // d.width, bad[0] % 4, got[bad[0]], exp["argb"][bad[0]])
+
+
+@pytest.mark.parametrize("misalign", [0, 1])
+def test_alpha_planes_through_both_paths(misalign):
+    """Frames with an alpha plane: interior chunks take the alpha bytes as one dword per four pixels and patch them into the
+    converted pixels; ragged chunks, widths that are not a multiple of 4 and planes that do not start on a 4-byte boundary
+    (misalign) take the general path with its byte loads."""
+    from packed_util import RawBatch
+    from test_gpu_packed_random import make_frame
+    from oracle import oracle
+    from webp_amd._lib import check, lib
+    rng = np.random.default_rng(4321 + misalign)
+    shapes = [(w, h) for (w, h, _, _) in SHAPES]
+    frames = [make_frame(rng, w, h, False) for (w, h) in shapes]
+    b = RawBatch(shapes, frames, [2] * len(frames), visible=[(vw, vh) for (_, _, vw, vh) in SHAPES])
+    ao = misalign
+    alphas = []
+    for i in range(b.n):
+        d = b.desc[i]
+        d.has_alpha, d.alpha_off = 1, ao
+        a = rng.integers(0, 256, d.width * d.height, dtype=np.uint8)
+        a[rng.random(a.size) < 0.3] = 255
+        alphas.append(a)
+        ao += (a.size + 255) // 256 * 256
+    alpha = np.zeros(ao + 256, np.uint8)
+    for i in range(b.n):
+        alpha[b.desc[i].alpha_off:b.desc[i].alpha_off + alphas[i].size] = alphas[i]
+    y = np.zeros(b.y_bytes, np.uint8); u = np.zeros(b.u_bytes, np.uint8); v = np.zeros(b.v_bytes, np.uint8)
+    argb = np.zeros(b.argb_bytes, np.uint8)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    check(lib().wp_vp8_decode_to_argb(b.n, b.desc, p(b.mb), b.n_mb, p(b.filt), p(b.coeff), b.n_coeff_blocks, p(y), p(u), p(v), p(alpha), p(argb)))
+    for i, (w, h) in enumerate(shapes):
+        exp = b.expected(i)
+        d = b.desc[i]
+        want = oracle.yuv420_to_argb(exp["y"], 16 * w, exp["u"], exp["v"], 8 * w, alphas[i], d.width, d.height)
+        got = argb[d.argb_off:d.argb_off + 4 * d.width * d.height]
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "frame %d (%dx%d): %d ARGB bytes differ, first at pixel (%d, %d) channel %d: got %d want %d" % (
+            i, d.width, d.height, bad.size, (bad[0] // 4) % d.width, (bad[0] // 4) // d.width, bad[0] % 4, got[bad[0]], want[bad[0]])

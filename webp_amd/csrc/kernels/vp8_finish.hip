@@ -71,7 +71,7 @@ void vp8_finish_kernel(const wp_vp8_frame* __restrict__ frames, const uint8_t* _
     if (WP_FINISH_FAST && finish_is_interior(fr, ty, c_first + (n_here - 1) * kFinishCols, shifted, Yp, Up, Vp, Ap, out)) {
         // an interior chunk's 9 source tiles all exist, and the next chunk's start 8 tiles further on: the source is one pointer
         const u32x4* src = reinterpret_cast<const u32x4*>(finish_src(fr, ty, c_first, Rp, Sp, true).src);
-        FinishBases fb = finish_bases(fr, ty, c_first, Yp, Up, Vp, out);
+        FinishBases fb = finish_bases(fr, ty, c_first, Yp, Up, Vp, Ap, out);
         u32x4 nx = {0u, 0u, 0u, 0u};
         if (t < kFinishTiles * (kTileBytes / 16)) nx = WP_NT_LOAD(src + t);
 #pragma unroll

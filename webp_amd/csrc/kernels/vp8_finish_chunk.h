@@ -93,6 +93,8 @@ __device__ __forceinline__ void finish_emit(const wp_vp8_frame& fr, int ty, int 
                 const ChromaTerms t1 = chroma_terms(int(u2 >> 8), int(v2 >> 8));
                 const bool any_tie = __builtin_amdgcn_ballot_w64(t0.tie || t1.tie) != 0;
                 const uint32_t pix0 = uint32_t(py0) * uint32_t(width) + uint32_t(px);
+                // both rows' alpha dwords are aligned when the plane and its rows are (px is a multiple of 4)
+                const bool a_dword = A != nullptr && npx == 4 && ((reinterpret_cast<uintptr_t>(A) | uint32_t(width)) & 3) == 0;
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
                     const int py = py0 + rr;
@@ -100,8 +102,12 @@ __device__ __forceinline__ void finish_emit(const wp_vp8_frame& fr, int ty, int 
                     const uint32_t pix = pix0 + (rr ? uint32_t(width) : 0u);
                     uint32_t a4 = 0xffffffffu;
                     if (A) {
-                        a4 = 0;
-                        for (int j = 0; j < npx; ++j) a4 |= uint32_t(A[size_t(pix + uint32_t(j))]) << (8 * j);
+                        if (a_dword) {
+                            a4 = *reinterpret_cast<const uint32_t*>(A + size_t(pix));     // the usual case: one load for the four pixels
+                        } else {
+                            a4 = 0;
+                            for (int j = 0; j < npx; ++j) a4 |= uint32_t(A[size_t(pix + uint32_t(j))]) << (8 * j);
+                        }
                     }
                     const uint4 o = convert_row4(rr ? yb : ya, t0, t1, a4, any_tie);
                     uint8_t* p = dst + size_t(pix * 4u);
@@ -137,7 +143,8 @@ __device__ __forceinline__ void finish_emit(const wp_vp8_frame& fr, int ty, int 
 __device__ __forceinline__ bool finish_is_interior(const wp_vp8_frame& fr, int ty, int c0, bool shifted, const uint8_t* Yp, const uint8_t* Up,
                                                    const uint8_t* Vp, const uint8_t* Ap, const uint8_t* out) {
     const int row0 = 16 * ty - (shifted ? kFiltShift : 0);
-    return shifted && Yp != nullptr && Up != nullptr && Vp != nullptr && out != nullptr && !(Ap != nullptr && fr.has_alpha) && row0 >= 0 &&
+    const bool alpha_ok = !(Ap != nullptr && fr.has_alpha) || ((reinterpret_cast<uintptr_t>(Ap) + fr.alpha_off) & 3) == 0;      // (rows are aligned with it: width % 4 == 0 below)
+    return shifted && Yp != nullptr && Up != nullptr && Vp != nullptr && out != nullptr && alpha_ok && row0 >= 0 &&
            row0 + 16 <= fr.height && c0 + kFinishCols <= fr.width && (fr.width & 3) == 0 &&
            ((reinterpret_cast<uintptr_t>(out) + fr.argb_off) & 15) == 0;
 }
@@ -146,10 +153,11 @@ __device__ __forceinline__ bool finish_is_interior(const wp_vp8_frame& fr, int t
 // for, four times per chunk).
 struct FinishBases {
     uint8_t *y, *argb, *u, *v;          // first byte of the chunk's first row in each output
+    const uint8_t* alpha;               // ... and in the alpha plane (null: opaque)
     uint32_t ystride, cstride, width;
-    __device__ __forceinline__ void next_chunk() { y += kFinishCols; argb += 4 * kFinishCols; u += kFinishCols / 2; v += kFinishCols / 2; }
+    __device__ __forceinline__ void next_chunk() { y += kFinishCols; argb += 4 * kFinishCols; u += kFinishCols / 2; v += kFinishCols / 2; if (alpha) alpha += kFinishCols; }
 };
-__device__ __forceinline__ FinishBases finish_bases(const wp_vp8_frame& fr, int ty, int c0, uint8_t* Yp, uint8_t* Up, uint8_t* Vp, uint8_t* out) {
+__device__ __forceinline__ FinishBases finish_bases(const wp_vp8_frame& fr, int ty, int c0, uint8_t* Yp, uint8_t* Up, uint8_t* Vp, const uint8_t* Ap, uint8_t* out) {
     FinishBases b;
     b.ystride = 16u * uint32_t(fr.mbw); b.cstride = 8u * uint32_t(fr.mbw); b.width = uint32_t(fr.width);
     const uint32_t row0 = uint32_t(16 * ty - kFiltShift);                          // first luma row of the chunk (interior: >= 0)
@@ -157,6 +165,7 @@ __device__ __forceinline__ FinishBases finish_bases(const wp_vp8_frame& fr, int 
     b.argb = out + fr.argb_off + 4u * size_t(row0 * b.width + uint32_t(c0));
     const size_t coff = size_t((row0 >> 1) * b.cstride + (uint32_t(c0) >> 1));
     b.u = Up + fr.u_off + coff; b.v = Vp + fr.v_off + coff;
+    b.alpha = (Ap != nullptr && fr.has_alpha) ? Ap + fr.alpha_off + size_t(row0 * b.width + uint32_t(c0)) : nullptr;
     return b;
 }
 // A wavefront that holds the chroma pair whose green term needs the Y-dependent tie correction (wp_convert.h) patches the
@@ -187,6 +196,7 @@ __device__ __forceinline__ void finish_emit_interior(const FinishBases& fb, int 
         __builtin_amdgcn_sched_barrier(0);      // one row at a time: interleaved, the two conversions need 38 registers (budget: 32)
         uint4 o0 = convert_row4_opaque(ya, cp0, cp1);
         if (any_tie) tie_patch_row4(o0, ya, t0.tie, t1.tie);
+        if (fb.alpha) alpha_patch_row4(o0, *reinterpret_cast<const uint32_t*>(fb.alpha + (po >> 2)));
         const u32x4 w0 = {o0.x, o0.y, o0.z, o0.w};
         WP_ARGB_STORE(reinterpret_cast<u32x4*>(fb.argb + po), w0);
 #if WP_FINISH_PRIO_LO != WP_FINISH_PRIO && WP_FINISH_LO_AT == 1
@@ -195,6 +205,7 @@ __device__ __forceinline__ void finish_emit_interior(const FinishBases& fb, int 
         __builtin_amdgcn_sched_barrier(0);
         uint4 o1 = convert_row4_opaque(yb, cp0, cp1);
         if (any_tie) tie_patch_row4(o1, yb, t0.tie, t1.tie);
+        if (fb.alpha) alpha_patch_row4(o1, *reinterpret_cast<const uint32_t*>(fb.alpha + fb.width + (po >> 2)));
         const u32x4 w1 = {o1.x, o1.y, o1.z, o1.w};
         WP_ARGB_STORE(reinterpret_cast<u32x4*>(fb.argb + 4u * fb.width + po), w1);
 #if WP_FINISH_PRIO_LO != WP_FINISH_PRIO && WP_FINISH_LO_AT == 2

@@ -93,6 +93,13 @@ __device__ __forceinline__ void tie_patch_row4(uint4& o, uint32_t y4, bool tie0,
     o.z -= (tie1 && ((y4 >> 16) & 0xffu) - 111u <= 35u) ? 0x00010000u : 0u;
     o.w -= (tie1 && (y4 >> 24) - 111u <= 35u) ? 0x00010000u : 0u;
 }
+// Frames with an alpha plane: the four alpha bytes of the row replace the opaque ones (one v_bfi_b32 per pixel)
+__device__ __forceinline__ void alpha_patch_row4(uint4& o, uint32_t a4) {
+    o.x = (o.x & 0xffffff00u) | (a4 & 0xffu);
+    o.y = (o.y & 0xffffff00u) | ((a4 >> 8) & 0xffu);
+    o.z = (o.z & 0xffffff00u) | ((a4 >> 16) & 0xffu);
+    o.w = (o.w & 0xffffff00u) | (a4 >> 24);
+}
 __device__ __forceinline__ uint4 convert_row4_opaque(uint32_t y4, const ChromaPairs& c0, const ChromaPairs& c1) {
     const uint32_t y02 = y4 & 0x00ff00ffu, y13 = (y4 >> 8) & 0x00ff00ffu;
     return make_uint4(convert_px_opaque<0>(y02, c0), convert_px_opaque<0>(y13, c0), convert_px_opaque<1>(y02, c1), convert_px_opaque<1>(y13, c1));
