@@ -190,11 +190,13 @@ int wp_vp8_pipeline_submit(wp_vp8_pipeline* p, int n, const wp_vp8_frame* fh, co
     rc = new_event(p, &s.mb0); if (rc) return rc;
     rc = new_event(p, &s.mb1); if (rc) { free_step_events(s); return rc; }
     s.started = p->d_started + 64 * (p->k % kCounters);                         // (256 bytes apart: a line of its own)
-    HIP_TRY(hipMemsetAsync(s.started, 0, sizeof(uint32_t), p->s_main));
-    HIP_TRY(hipEventRecord(s.mb0, p->s_main));
+    hipError_t he = hipMemsetAsync(s.started, 0, sizeof(uint32_t), p->s_main);
+    if (he == hipSuccess) he = hipEventRecord(s.mb0, p->s_main);
+    if (he != hipSuccess) { free_step_events(s); return hip_fail(he, "pipeline step set-up"); }
     rc = wpk_vp8_recon_filter_counted(n, s.fh.data(), fd, d_mb, d_filt, d_coeff, s.work, p->ws_bytes, p->s_main, s.started, &s.workgroups);
     if (rc) { free_step_events(s); return rc; }
-    HIP_TRY(hipEventRecord(s.mb1, p->s_main));
+    he = hipEventRecord(s.mb1, p->s_main);
+    if (he != hipSuccess) { free_step_events(s); return hip_fail(he, "hipEventRecord"); }
     p->k += 1;
     // the finishing pass of the step before goes out now, beside the kernel just launched
     if (p->has_pending) { rc = enqueue_finish(p, &s); if (rc) { free_step_events(s); return rc; } }
