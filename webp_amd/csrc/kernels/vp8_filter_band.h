@@ -230,6 +230,23 @@ __device__ __forceinline__ void filter_line_d(uint32_t (&v)[N], bool mb_edge, bo
         normal_edge_f<true, true>(v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19], thr, il, hl, inner);
     }
 }
+// the simple filter (filter2, Filter.hx:29-50) likewise: luma only, one edge position
+__device__ __forceinline__ void simple_edge_d(uint32_t p1, uint32_t& p0, uint32_t& q0, uint32_t q1, float thr, bool use) {
+    const float e0 = fsample(q0) - fsample(p0), d1 = fsample(p1) - fsample(q1);
+    const bool on = use & (fma_abs4(e0, d1) <= thr);
+    const float lim = __uint_as_float(127u);
+    const float wf = __builtin_fmaf(e0, 3.0f, __builtin_amdgcn_fmed3f(d1, -lim, lim));
+    const int a = f_to_int<true>(on ? wf : 0.0f);
+    p0 = fclamp255<true>(p0 + uint32_t(clamp15((a + 3) >> 3)));
+    q0 = fclamp255<true>(q0 - uint32_t(clamp15((a + 4) >> 3)));
+}
+__device__ __forceinline__ void simple_line_d(uint32_t (&v)[20], bool mb_edge, bool inner, int level) {
+    const float thr = __uint_as_float(uint32_t(2 * level + 1)), thr_mb = __uint_as_float(uint32_t(2 * level + 9));
+    simple_edge_d(v[2], v[3], v[4], v[5], thr_mb, mb_edge);
+    simple_edge_d(v[6], v[7], v[8], v[9], thr, inner);
+    simple_edge_d(v[10], v[11], v[12], v[13], thr, inner);
+    simple_edge_d(v[14], v[15], v[16], v[17], thr, inner);
+}
 __device__ __forceinline__ void unpack4u(uint32_t w, uint32_t* v) { v[0] = w & 0xff; v[1] = (w >> 8) & 0xff; v[2] = (w >> 16) & 0xff; v[3] = w >> 24; }
 __device__ __forceinline__ uint32_t pack4u(const uint32_t* v) { return v[0] | v[1] << 8 | v[2] << 16 | v[3] << 24; }
 // bytes of a dword -> four biased samples, and back (the clamped bit patterns carry the sample in their low byte)

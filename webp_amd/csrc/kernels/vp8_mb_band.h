@@ -414,7 +414,14 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
                             wc = make_uint2(pack4f(v + 4), pack4f(v + 8));
                         }
                     }
-                } else if (ftype != 0 && do_filter) {
+                } else if (kFilterDen && ftype == 1 && do_filter) {
+                    uint32_t v[20];
+                    unpack4u(t32(&F.y[4 + l][pb + 12]), v);
+                    unpack4u(w.x, v + 4); unpack4u(w.y, v + 8); unpack4u(w.z, v + 12); unpack4u(w.w, v + 16);
+                    simple_line_d(v, x > 0, inner, level);
+                    t32(&F.y[4 + l][pb + 12]) = pack4u(v);
+                    w = make_uint4(pack4u(v + 4), pack4u(v + 8), pack4u(v + 12), pack4u(v + 16));
+                } else if (!kFilterDen && ftype != 0 && do_filter) {
                     {
                         int v[20];
                         unpack4(t32(&F.y[4 + l][pb + 12]), v);
@@ -461,7 +468,14 @@ __device__ __forceinline__ void mb_band(const wp_vp8_frame& fr, int band, int n_
 #pragma unroll
                         for (int k = 1; k < 11; ++k) F.c[lp][k][cb8 + lr] = uint8_t(v[k]);
                     }
-                } else if (do_filter) {
+                } else if (kFilterDen && ftype == 1 && do_filter) {
+                    uint32_t v[20];
+#pragma unroll
+                    for (int k = 0; k < 20; ++k) v[k] = F.y[k][cb + l];
+                    simple_line_d(v, y > 0, inner, level);
+#pragma unroll
+                    for (int k = 3; k < 17; ++k) F.y[k][cb + l] = uint8_t(v[k]);      // (the simple filter changes p0 and q0 only: rows 3, 4, 7, 8, ...)
+                } else if (!kFilterDen && do_filter) {
                     // ---- horizontal edges: lane = pixel column; rows -4..15 relative to the MB ----
                     {
                         int v[20];
